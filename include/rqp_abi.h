@@ -1,0 +1,174 @@
+/*
+ * rqp_abi.h -- C ABI of librqp_hip.so, the MI355X (gfx950) ReLU-QP hot path.
+ *
+ * The reference (gstoica27/ReLUQP-py) has NO foreign-function interface: its hot
+ * path is the Python class reluqp.reluqpth.ReLU_QP calling torch.  This header is
+ * therefore the boundary a maintainer would bind *under* that class (ctypes stub in
+ * INTEGRATION.md); each entry point names the reference method it replaces
+ * (paths relative to /root/reference/ReLU-QP-py/reluqp/).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types cross the ABI.
+ *  - Every `const void*` / `void*` data pointer is a DEVICE pointer (e.g.
+ *    torch.Tensor.data_ptr()) of element type `dims.dtype` unless stated; the caller
+ *    owns all of them.  The library owns only its workspace (packed H/A copies, the
+ *    K(rho) table, per-instance ADMM state), allocated in rqp_setup, freed in
+ *    rqp_destroy.
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream).  All work is
+ *    enqueued on it; nothing synchronises the host except where stated.
+ *  - Every function returns 0 on success or a negative rqp_error; nothing throws.
+ *  - A handle is not thread-safe: one handle per host thread / GPU.
+ *  - Batched: every instance b in [0,batch) has its own g,l,u, state, rho index,
+ *    iteration count and exit; H and A are per instance, or shared by all instances
+ *    (dims.shared_mats = 1, then H is [n,n] and A is [m,n]).
+ */
+#ifndef RQP_ABI_H
+#define RQP_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rqp_handle rqp_handle;
+
+enum rqp_dtype { RQP_F32 = 0, RQP_F64 = 1 };
+
+enum rqp_error {
+    RQP_OK = 0,
+    RQP_ERR_ARG = -1,        /* null pointer / bad dimension / bad setting       */
+    RQP_ERR_STATE = -2,      /* call order (e.g. solve before setup)             */
+    RQP_ERR_HIP = -3,        /* a HIP runtime call failed: see rqp_last_error    */
+    RQP_ERR_OOM = -4,        /* workspace allocation failed                      */
+    RQP_ERR_UNSUPPORTED = -5 /* e.g. Hx/Ax matrix update (reluqpth.py:177)       */
+};
+
+/* per-instance exit status written to rqp_info.status (reluqpth.py:236,245) */
+enum rqp_status {
+    RQP_STATUS_SOLVED = 0,          /* "solved"             */
+    RQP_STATUS_MAX_ITER = 1,        /* "max_iters_reached"  */
+    RQP_STATUS_UNSOLVED = -1        /* never solved          */
+};
+
+typedef struct rqp_dims {
+    int32_t n;            /* decision variables   (QP.nx, classes.py:29)              */
+    int32_t m;            /* constraints          (QP.nc, classes.py:30)              */
+    int32_t batch;        /* independent instances (>= 1)                             */
+    int32_t shared_mats;  /* 1: one (H, A) shared by all instances (linear MPC)       */
+    int32_t dtype;        /* rqp_dtype of every data pointer                          */
+    int32_t reserved;
+} rqp_dims;
+
+/* Settings of classes.py:32-65 that reach the device (same names, same defaults). */
+typedef struct rqp_settings {
+    double rho;                    /* 0.1   */
+    double rho_min;                /* 1e-6  */
+    double rho_max;                /* 1e6   */
+    double sigma;                  /* 1e-6  */
+    double adaptive_rho_tolerance; /* 5     */
+    double eps_abs;                /* 1e-3  */
+    double eq_tol;                 /* 1e-6  */
+    int32_t adaptive_rho;          /* 1     */
+    int32_t max_iter;              /* 4000  */
+    int32_t check_interval;        /* 25    */
+    int32_t warm_starting;         /* 1     */
+} rqp_settings;
+
+/* Per-instance results of one solve (classes.py:67-88), struct of DEVICE arrays,
+ * each of length `batch`; any pointer may be NULL to skip that field.           */
+typedef struct rqp_info {
+    int32_t* iter;         /* Info.iter                                             */
+    int32_t* status;       /* rqp_status                                            */
+    int32_t* rho_ind;      /* rho index after the solve (ReLU_QP.rho_ind)           */
+    double* pri_res;       /* Info.pri_res                                          */
+    double* dua_res;       /* Info.dua_res                                          */
+    double* rho_estimate;  /* Info.rho_estimate                                     */
+    double* obj_val;       /* Info.obj_val = 1/2 x'Hx + g'x   (reluqpth.py:320-322)  */
+    /* optional per-check trace, [batch][trace_cap][4] doubles:
+     * (pri, dua, rho_estimate, rho index before the move), check c = iteration
+     * (c+1)*check_interval; rows past the last check are left untouched.         */
+    double* trace;
+    int32_t trace_cap;
+    int32_t reserved;
+} rqp_info;
+
+/* Fill *s with the defaults of classes.py:32-65. */
+int rqp_default_settings(rqp_settings* s);
+
+/* ReLU_QP.__init__ + Settings (reluqpth.py:93-100,128-142): validates dims and
+ * settings, builds the rho ladder (setup_rhos, reluqpth.py:20-38) and binds `device`. */
+int rqp_create(rqp_handle** out, const rqp_dims* dims, const rqp_settings* settings, int device);
+
+/* ReLU_QP.setup (reluqpth.py:102-157): QP.__init__ casts (classes.py:4-30), the
+ * per-rho KKT inverses of ReLU_Layer.setup_matrices (reluqpth.py:40-78; here
+ * K_j = (H + sigma I + A' diag(rho_j c) A)^-1 for every ladder entry, c_i = 1e3 on
+ * rows with u_i - l_i <= eq_tol), zero state and rho_ind = argmin|rhos - rho|.
+ * H [batch|1][n][n], g [batch][n], A [batch|1][m][n], l,u [batch][m], row-major.  */
+int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const void* l,
+              const void* u, void* stream);
+
+/* ReLU_QP.update (reluqpth.py:159-183): new g and/or l and/or u ([batch][n] /
+ * [batch][m]); NULL = unchanged.  Matrix updates are RQP_ERR_UNSUPPORTED upstream
+ * (reluqpth.py:177) and have no entry point here.  State is untouched.          */
+int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void* stream);
+
+/* ReLU_QP.update_settings (reluqpth.py:185-199): only max_iter, eps_abs and
+ * check_interval may change after setup; a difference in any other field returns
+ * RQP_ERR_ARG (the reference raises ValueError).                                  */
+int rqp_update_settings(rqp_handle* h, const rqp_settings* settings);
+
+/* ReLU_QP.warm_start (reluqpth.py:251-276) with Q6 fixed (values are written into
+ * the iterate).  x [batch][n], z, lam [batch][m]; NULL = unchanged.  `rho` selects
+ * rho_ind = argmin|rhos - rho| for every instance when has_rho != 0.              */
+int rqp_warm_start(rqp_handle* h, const void* x, const void* z, const void* lam, int has_rho,
+                   double rho, void* stream);
+
+/* ReLU_QP.clear_primal_dual (reluqpth.py:324-333): zero state, reset rho index.  */
+int rqp_clear_primal_dual(rqp_handle* h, void* stream);
+
+/* ReLU_QP.solve + update_results (reluqpth.py:201-249,278-305): the whole ADMM
+ * loop of every instance -- iterate (jit_forward :84-89), every check_interval
+ * iterations compute_residuals (:307-318), rho-index move (:223-227), termination
+ * (:233) -- in ONE kernel launch, one workgroup per instance, no host round trip.
+ * Writes x [batch][n], z [batch][m], lam [batch][m] (the state's dual, Q7/Q16) and
+ * *info; any of them may be NULL.  Asynchronous on `stream`.                      */
+int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, void* stream);
+
+/* k plain iterations at each instance's current rho index, no checks: exactly k
+ * applications of ReLU_Layer.forward (reluqpth.py:80-89).  For parity tests.     */
+int rqp_iterate(rqp_handle* h, int32_t k, void* stream);
+
+/* ReLU_QP.compute_residuals + compute_J (reluqpth.py:307-322) on the current
+ * state with carried estimate rho_in (host scalar): pri, dua, rho_out, obj are
+ * device arrays [batch] of doubles (NULL to skip).                               */
+int rqp_compute_residuals(rqp_handle* h, double rho_in, double* pri, double* dua,
+                          double* rho_out, double* obj, void* stream);
+
+/* Copy the current state out (x [batch][n], z, lam [batch][m] in dims.dtype,
+ * rho_ind [batch] int32); NULL to skip.                                           */
+int rqp_get_state(rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, void* stream);
+
+/* The rho ladder (host doubles).  *count receives its length; rhos may be NULL.  */
+int rqp_get_rhos(const rqp_handle* h, double* rhos, int32_t cap, int32_t* count);
+
+/* K_j of instance b (ReLU_Layer.kkt_rhs_invs[j], reluqpth.py:56) -> out [n][n]
+ * in dims.dtype (device pointer).  For parity tests.                              */
+int rqp_get_K(rqp_handle* h, int32_t b, int32_t j, void* out, void* stream);
+
+/* Which solve kernel the handle dispatches to ("generic", "resident", ...).       */
+const char* rqp_kernel_name(const rqp_handle* h);
+
+int rqp_destroy(rqp_handle* h);
+
+const char* rqp_strerror(int err);
+/* Text of the last failure on this handle (HIP error string etc.).                */
+const char* rqp_last_error(const rqp_handle* h);
+/* Library / ABI version, e.g. "rqp-hip 0.1 gfx950".                               */
+const char* rqp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQP_ABI_H */

@@ -1,0 +1,346 @@
+// rqp_admm.hip -- the ADMM hot loop of ReLU_QP.solve (reference
+// ReLU-QP-py/reluqp/reluqpth.py:201-249), GENERIC variant: any (n, m), float or double,
+// matrices streamed from global memory (L2 / Infinity Cache / HBM) every iteration.
+//
+// One workgroup (256 threads = 4 wavefronts) owns one QP instance for its whole solve:
+// iterate (jit_forward :84-89), every check_interval iterations the residuals
+// (compute_residuals :307-318), the rho-index move (:223-227) and the termination test
+// (:233), then update_results (:278-305) -- one launch, no host round trip.
+//
+// The iterate is the residual-correction statement of SURVEY.md Appendix A.2
+// (oracle/reluqp_oracle.py: forward_refine): with K = (H + sigma I + A' rho A)^-1,
+//     p = A x - z ; lam_hat = lam + rho p ; nu = lam_hat + rho p
+//     d = H x + g + A' nu ; dx = -K d ; x += dx ; (A x) += A dx
+//     z = clamp(A x + lam_hat / rho, l, u) ; lam = lam_hat
+// Vector state (x, z, lam, A x) is accumulated in float64 in LDS; the four matrix-vector
+// products run in T.  Algebraically this is exactly W s + b of reluqpth.py:71-77.
+#include "rqp_common.h"
+
+template <typename T>
+struct VecT;
+template <>
+struct VecT<float> {
+    typedef float4 type;
+    static constexpr int W = 4;
+};
+template <>
+struct VecT<double> {
+    typedef double2 type;
+    static constexpr int W = 2;
+};
+
+__device__ __forceinline__ void vload(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void vload(const double* p, double (&v)[2]) {
+    double2 t = *reinterpret_cast<const double2*>(p);
+    v[0] = t.x; v[1] = t.y;
+}
+
+// torch.max / vector_norm(inf) semantics: NaN propagates
+template <typename T>
+__device__ __forceinline__ T tmax(T a, T b) {
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+
+// out[c] = sum_r Mat[r][c] * w[r]   (Mat row-major [R][ld], ld % W == 0, pad columns zero)
+// Threads = (column group of W columns) x (row slice); partial sums meet in LDS `part`.
+// `w`, `out`, `part` are LDS; ends with a barrier (out is complete and `w` may be reused).
+template <typename T>
+__device__ void colmv(const T* __restrict__ Mat, int ld, int R, int C, const T* w, T* out, T* part) {
+    constexpr int W = VecT<T>::W;
+    const int tid = threadIdx.x;
+    const int CG = (C + W - 1) / W;
+    for (int cg0 = 0; cg0 < CG; cg0 += RQP_NT) {
+        const int CGc = min(RQP_NT, CG - cg0);
+        const int RS = RQP_NT / CGc;
+        const int cg = tid % CGc, rs = tid / CGc;
+        T acc[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] = T(0);
+        if (rs < RS) {
+            const T* base = Mat + (size_t)(cg0 + cg) * W;
+#pragma unroll 4
+            for (int r = rs; r < R; r += RS) {
+                T v[W];
+                vload(base + (size_t)r * ld, v);
+                const T wr = w[r];
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc[e] = fma(v[e], wr, acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) part[(size_t)rs * (CGc * W) + cg * W + e] = acc[e];
+        }
+        __syncthreads();
+        for (int c = tid; c < CGc * W; c += RQP_NT) {
+            T s = T(0);
+            for (int q = 0; q < RS; ++q) s += part[(size_t)q * (CGc * W) + c];
+            if (cg0 * W + c < C) out[cg0 * W + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// NaN-propagating max over the workgroup of NV values per thread; result broadcast to all.
+template <typename T, int NV>
+__device__ void block_max(T (&v)[NV], T* red /* LDS [NV * 4] */) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] = tmax(v[e], (T)__shfl_xor(v[e], off, RQP_WAVE));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) red[wave * NV + e] = v[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        T r = red[e];
+        for (int w = 1; w < RQP_NT / RQP_WAVE; ++w) r = tmax(r, red[w * NV + e]);
+        v[e] = r;
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int W = VecT<T>::W;
+    const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int maxd = max(ldn, ldm);
+
+    // ---- LDS carve-up (host computes the same size: rqp_launch_solve_generic)
+    double* xs = (double*)smem_raw;       // [n]   x          (float64 accumulator)
+    double* zs = xs + n;                  // [m]   z
+    double* ls = zs + m;                  // [m]   lam
+    double* zts = ls + m;                 // [m]   A x        (float64 accumulator)
+    T* gT = (T*)(zts + m);                // [ldn]
+    T* lT = gT + ldn;                     // [ldm]
+    T* uT = lT + ldm;                     // [ldm]
+    T* rvT = uT + ldm;                    // [ldm] rho vector of the current index
+    T* cT = rvT + ldm;                    // [ldm] 1 / 1e3 equality scale
+    T* vin = cT + ldm;                    // [maxd] product input
+    T* hx = vin + maxd;                   // [ldn] H x
+    T* vn = hx + ldn;                     // [ldn] n-sized product output
+    T* dv = vn + ldn;                     // [ldn] d, then dx
+    T* vm = dv + ldn;                     // [ldm] m-sized product output
+    T* part = vm + ldm;                   // [RQP_NT * W]
+    T* red = part + RQP_NT * W;           // [8 * 4]
+
+    const T* Ht = (const T*)a.Ht + (size_t)b * a.sH;
+    const T* A = (const T*)a.A + (size_t)b * a.sA;
+    const T* At = (const T*)a.At + (size_t)b * a.sAt;
+    const T* Kb = (const T*)a.K + (size_t)b * a.sK;
+
+    for (int i = tid; i < n; i += RQP_NT) {
+        xs[i] = a.x[(size_t)b * n + i];
+        gT[i] = ((const T*)a.g)[(size_t)b * n + i];
+    }
+    for (int i = tid; i < m; i += RQP_NT) {
+        zs[i] = a.z[(size_t)b * m + i];
+        ls[i] = a.lam[(size_t)b * m + i];
+        lT[i] = ((const T*)a.l)[(size_t)b * m + i];
+        uT[i] = ((const T*)a.u)[(size_t)b * m + i];
+        cT[i] = ((const T*)a.c)[(size_t)b * m + i];
+    }
+    int ri = a.rho_ind[b];
+    T rho_est = (a.mode == 2) ? (T)a.rho_in : (T)a.rhos[ri];      // reluqpth.py:211
+    for (int i = tid; i < m; i += RQP_NT) rvT[i] = (T)a.rhos[ri] * cT[i];
+    for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
+    __syncthreads();
+    colmv<T>(At, ldm, n, m, vin, vm, part);                        // A x of the incoming state
+    for (int i = tid; i < m; i += RQP_NT) zts[i] = (double)vm[i];
+    __syncthreads();
+
+    bool hx_valid = false, converged = false;
+    int iters = 0;
+    T pri = T(0), dua = T(0);
+    const T tolT = (T)a.tol;
+    const int kmax = (a.mode == 2) ? 0 : a.max_iter;
+
+    // ---- residuals of the current state (compute_residuals, reluqpth.py:307-318) ----------
+    // leaves H x in hx (hx_valid), returns pri/dua and the new carried rho estimate
+    auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
+        for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
+        __syncthreads();
+        colmv<T>(Ht, ldn, n, n, vin, hx, part);                    // t2 = H x
+        for (int i = tid; i < m; i += RQP_NT) vin[i] = (T)ls[i];
+        __syncthreads();
+        colmv<T>(A, ldn, m, n, vin, vn, part);                     // t3 = A' lam
+        T v[7];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) v[e] = T(0);
+        for (int i = tid; i < m; i += RQP_NT) {
+            const T t1 = (T)zts[i], zi = (T)zs[i];
+            v[0] = tmax(v[0], (T)fabs((T)(zts[i] - zs[i])));       // |A x - z|
+            v[1] = tmax(v[1], (T)fabs(t1));
+            v[2] = tmax(v[2], (T)fabs(zi));
+        }
+        for (int i = tid; i < n; i += RQP_NT) {
+            v[3] = tmax(v[3], (T)fabs(hx[i] + vn[i] + gT[i]));     // |H x + A' lam + g|
+            v[4] = tmax(v[4], (T)fabs(hx[i]));
+            v[5] = tmax(v[5], (T)fabs(vn[i]));
+            v[6] = tmax(v[6], (T)fabs(gT[i]));
+        }
+        block_max<T, 7>(v, red);
+        o_pri = v[0];
+        o_dua = v[3];
+        const T num = v[0] / tmax(v[1], v[2]);                      // :315
+        const T den = v[3] / tmax(tmax(v[4], v[5]), v[6]);          // :316
+        T est = rho_carry * (T)sqrt(num / den);                    // :317
+        if (est < (T)a.rho_min) est = (T)a.rho_min;                // torch.clamp: NaN stays NaN
+        if (est > (T)a.rho_max) est = (T)a.rho_max;
+        return est;
+    };
+
+    for (int k = 1; k <= kmax; ++k) {
+        const T* Kj = Kb + (size_t)ri * n * ldn;
+        if (!hx_valid) {
+            for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
+            __syncthreads();
+            colmv<T>(Ht, ldn, n, n, vin, hx, part);                // H x
+        }
+        for (int i = tid; i < m; i += RQP_NT) {
+            const double rv = (double)rvT[i];
+            const double p = zts[i] - zs[i];
+            const double lh = ls[i] + rv * p;                      // lam_hat
+            ls[i] = lh;
+            vin[i] = (T)(lh + rv * p);                             // nu
+        }
+        __syncthreads();
+        colmv<T>(A, ldn, m, n, vin, vn, part);                     // A' nu
+        for (int i = tid; i < n; i += RQP_NT) dv[i] = hx[i] + gT[i] + vn[i];   // d
+        __syncthreads();
+        colmv<T>(Kj, ldn, n, n, dv, vn, part);                     // K d
+        for (int i = tid; i < n; i += RQP_NT) {
+            const T dx = -vn[i];
+            xs[i] += (double)dx;
+            dv[i] = dx;
+        }
+        __syncthreads();
+        colmv<T>(At, ldm, n, m, dv, vm, part);                     // A dx
+        for (int i = tid; i < m; i += RQP_NT) {
+            const double zt = zts[i] + (double)vm[i];
+            zts[i] = zt;
+            const double v = zt + ls[i] / (double)rvT[i];
+            double zn = v;                                          // torch.clamp: NaN stays NaN
+            if (v < (double)lT[i]) zn = (double)lT[i];
+            if (v > (double)uT[i]) zn = (double)uT[i];
+            zs[i] = zn;
+        }
+        hx_valid = false;
+        iters = k;
+        __syncthreads();
+
+        if (a.mode == 0 && (k % a.check_interval) == 0) {          // :218 (Q3 fixed: always check)
+            const int ri_before = ri;
+            rho_est = residuals(rho_est, pri, dua);                // :220 (Q4: estimate is carried)
+            hx_valid = true;
+            if (rho_est > (T)a.rhos[ri] * tolT && ri < a.nrho - 1)           // :223
+                ri += 1;
+            else if (rho_est < (T)a.rhos[ri] / tolT && ri > 0)               // :226
+                ri -= 1;
+            if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && tid == 0) {
+                double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
+                tr[0] = (double)pri; tr[1] = (double)dua; tr[2] = (double)rho_est; tr[3] = (double)ri_before;
+            }
+            if (ri != ri_before) {
+                for (int i = tid; i < m; i += RQP_NT) rvT[i] = (T)a.rhos[ri] * cT[i];
+                __syncthreads();
+            }
+            if (pri < (T)a.thr_p && dua < (T)a.thr_d) {            // :233
+                converged = true;
+                break;
+            }
+        }
+    }
+
+    if (a.mode == 1) {                                             // iterate-only: keep the state
+        for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = xs[i];
+        for (int i = tid; i < m; i += RQP_NT) {
+            a.z[(size_t)b * m + i] = zs[i];
+            a.lam[(size_t)b * m + i] = ls[i];
+        }
+        return;
+    }
+    if (!converged) rho_est = residuals(rho_est, pri, dua);        // :243 (Q11 fixed: fresh state)
+
+    // objective 1/2 x'Hx + g'x (compute_J :320-322): hx holds H x of the final state
+    double jp = 0.0;
+    for (int i = tid; i < n; i += RQP_NT) jp += (double)((T)xs[i] * (T)(T(0.5) * hx[i] + gT[i]));
+    for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, RQP_WAVE);
+    double* redd = (double*)part;
+    if ((tid & 63) == 0) redd[tid >> 6] = jp;
+    __syncthreads();
+    const double obj = redd[0] + redd[1] + redd[2] + redd[3];
+
+    if (a.mode == 2) {
+        if (tid == 0) {
+            if (a.r_pri) a.r_pri[b] = (double)pri;
+            if (a.r_dua) a.r_dua[b] = (double)dua;
+            if (a.r_rho) a.r_rho[b] = (double)rho_est;
+            if (a.r_obj) a.r_obj[b] = obj;
+        }
+        return;
+    }
+
+    // ---- update_results (reluqpth.py:278-305)
+    if (a.out_x) for (int i = tid; i < n; i += RQP_NT) ((T*)a.out_x)[(size_t)b * n + i] = (T)xs[i];
+    if (a.out_z) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_z)[(size_t)b * m + i] = (T)zs[i];
+    if (a.out_lam) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_lam)[(size_t)b * m + i] = (T)ls[i];
+    if (tid == 0) {
+        if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+        if (a.info.rho_ind) a.info.rho_ind[b] = ri;
+        if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
+        if (a.info.dua_res) a.info.dua_res[b] = (double)dua;
+        if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
+        if (a.info.obj_val) a.info.obj_val[b] = obj;
+    }
+    if (a.warm_starting) {                                         // state + rho index persist (:304)
+        for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = xs[i];
+        for (int i = tid; i < m; i += RQP_NT) {
+            a.z[(size_t)b * m + i] = zs[i];
+            a.lam[(size_t)b * m + i] = ls[i];
+        }
+        if (tid == 0) a.rho_ind[b] = ri;
+    } else {                                                       // clear_primal_dual (:324-333)
+        for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = 0.0;
+        for (int i = tid; i < m; i += RQP_NT) {
+            a.z[(size_t)b * m + i] = 0.0;
+            a.lam[(size_t)b * m + i] = 0.0;
+        }
+        if (tid == 0) a.rho_ind[b] = a.rho_ind0;
+    }
+}
+
+static size_t generic_lds_bytes(const rqp_handle* h) {
+    const size_t W = (h->esz == 4) ? 4 : 2;
+    const size_t maxd = (size_t)(h->ldn > h->ldm ? h->ldn : h->ldm);
+    size_t dbl = (size_t)h->n + 3 * (size_t)h->m;
+    size_t t = 4 * (size_t)h->ldn /*gT hx vn dv*/ + 5 * (size_t)h->ldm /*lT uT rvT cT vm*/ + maxd + RQP_NT * W + 32;
+    return dbl * sizeof(double) + t * h->esz;
+}
+
+hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = generic_lds_bytes(h);
+    hipError_t e;
+    if (h->esz == 4) {
+        if (lds > 48 * 1024) {
+            e = hipFuncSetAttribute((const void*)k_admm_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        k_admm_generic<float><<<h->B, RQP_NT, lds, s>>>(a);
+    } else {
+        if (lds > 48 * 1024) {
+            e = hipFuncSetAttribute((const void*)k_admm_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        k_admm_generic<double><<<h->B, RQP_NT, lds, s>>>(a);
+    }
+    return hipGetLastError();
+}

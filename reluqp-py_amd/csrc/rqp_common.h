@@ -1,0 +1,88 @@
+// Internal declarations shared by the translation units of librqp_hip.so.
+// gfx950 (MI355X, CDNA4) only.  Not installed; the public boundary is include/rqp_abi.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rqp_abi.h"
+
+#define RQP_NT 256          // threads per workgroup of the generic kernels (4 wavefronts)
+#define RQP_WAVE 64         // CDNA wavefront
+
+// ---------------------------------------------------------------------------------------
+// Workspace layout (all device memory, owned by the handle).  T = float | double.
+//   Ht  [nmat][n][ldn]   T   H transposed (so that H x is a column-oriented product for any H)
+//   A   [nmat][m][ldn]   T   row-major, leading dim padded to a multiple of 16 B
+//   At  [nmat][n][ldm]   T   A transposed
+//   K   [nmat][nrho][n][ldn] T  K_j = (H + sigma I + A' diag(rho_j c) A)^-1, symmetric
+//   G   [nmat][n][n]     double  A' diag(c) A   (setup only)
+//   g   [B][n], l,u,c [B][m]   T   (c_i = 1e3 on equality rows else 1)
+//   x   [B][n], z,lam [B][m]   double   ADMM state (float64 accumulators)
+//   rho_ind [B] int32
+// nmat = 1 when dims.shared_mats else B.
+// ---------------------------------------------------------------------------------------
+struct rqp_handle {
+    rqp_dims dims;
+    rqp_settings st;
+    int device = 0;
+    int n = 0, m = 0, B = 0, ldn = 0, ldm = 0, nrho = 0, rho_ind0 = 0, nmat = 0;
+    size_t esz = 4;
+    bool is_setup = false;
+    std::vector<double> rhos;
+
+    void *Ht = nullptr, *A = nullptr, *At = nullptr, *K = nullptr;
+    void *g = nullptr, *l = nullptr, *u = nullptr, *c = nullptr;
+    double* G = nullptr;
+    double *x = nullptr, *z = nullptr, *lam = nullptr;
+    int32_t* rho_ind = nullptr;
+    double* rhos_d = nullptr;
+    double* fscratch = nullptr;   // factor workspace when n*n doubles exceed LDS
+    size_t fscratch_elems = 0;
+
+    const char* kernel_name = "generic";
+    std::string err;
+};
+
+// kernel argument blocks (POD, passed by value) --------------------------------------------
+struct SolveArgs {
+    int n, m, ldn, ldm, nrho, B;
+    int max_iter, check_interval, warm_starting, rho_ind0;
+    int mode;                 // 0 solve, 1 iterate-only (k = max_iter), 2 residuals-only
+    double sigma, tol, rho_min, rho_max, thr_p, thr_d, rho_in;
+    const void *Ht, *A, *At, *K;
+    size_t sH, sA, sAt, sK;   // per-instance strides in elements (0 when shared)
+    const void *g, *l, *u, *c;
+    const double* rhos;
+    double *x, *z, *lam;
+    int32_t* rho_ind;
+    void *out_x, *out_z, *out_lam;
+    rqp_info info;
+    double *r_pri, *r_dua, *r_rho, *r_obj;   // mode 2 outputs
+};
+
+struct SetupArgs {
+    int n, m, ldn, ldm, nrho, B, nmat;
+    double sigma, eq_tol;
+    const void *H_in, *A_in, *g_in, *l_in, *u_in;
+    void *Ht, *A, *At, *K, *g, *l, *u, *c;
+    double* G;
+    const double* rhos;
+    double* fscratch;
+};
+
+// launchers (defined in the .hip files); return hipError_t of the launch
+hipError_t rqp_launch_pack(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_vec_update(const rqp_handle* h, const void* g, const void* l, const void* u, hipStream_t s);
+hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* z, const void* lam, int set_rho,
+                                int rho_ind, hipStream_t s);
+hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
+hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
+
+static inline int rqp_round_up(int v, int q) { return (v + q - 1) / q * q; }

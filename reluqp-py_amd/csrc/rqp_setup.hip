@@ -1,0 +1,290 @@
+// rqp_setup.hip -- one-time factorisation path of ReLU_QP.setup (reference
+// ReLU-QP-py/reluqp/reluqpth.py:102-157 -> ReLU_Layer.setup_matrices :40-78).
+//
+// The reference builds, for each of the ~18 rho values, a dense (n+2m)^2 matrix W.
+// Here only K_j = (H + sigma I + rho_j A' diag(c) A)^-1 (n x n) is built per rho
+// (SURVEY.md Appendix A): G = A' diag(c) A once, then M_j = sym(H) + sigma I + rho_j G
+// is inverted in float64 by an in-place Gauss-Jordan sweep (M_j is SPD: no pivoting).
+//
+// Kernels: k_pack (casts/transposes, QP.__init__ classes.py:4-30), k_gram, k_factor,
+// plus the small state/vector movers behind update()/warm_start()/get_state().
+#include "rqp_common.h"
+
+// ------------------------------------------------------------------------------ pack
+// Ht[r][c] = H[c][r]; A copied with padded leading dim; At[r][c] = A[c][r]; pads zeroed.
+template <typename T>
+__global__ void k_pack_mats(SetupArgs a) {
+    const int mat = blockIdx.y;
+    const T* H = (const T*)a.H_in + (size_t)mat * a.n * a.n;
+    const T* A = (const T*)a.A_in + (size_t)mat * a.m * a.n;
+    T* Ht = (T*)a.Ht + (size_t)mat * a.n * a.ldn;
+    T* Ap = (T*)a.A + (size_t)mat * a.m * a.ldn;
+    T* At = (T*)a.At + (size_t)mat * a.n * a.ldm;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < a.n * a.ldn; i += nth) {
+        int r = i / a.ldn, c = i % a.ldn;
+        Ht[i] = (c < a.n) ? H[(size_t)c * a.n + r] : T(0);
+    }
+    for (int i = tid; i < a.m * a.ldn; i += nth) {
+        int r = i / a.ldn, c = i % a.ldn;
+        Ap[i] = (c < a.n) ? A[(size_t)r * a.n + c] : T(0);
+    }
+    for (int i = tid; i < a.n * a.ldm; i += nth) {
+        int r = i / a.ldm, c = i % a.ldm;
+        At[i] = (c < a.m) ? A[(size_t)c * a.n + r] : T(0);
+    }
+}
+
+// g, l, u copies and the equality-row scale c (reluqpth.py:54: rho*1e3 where u-l <= eq_tol)
+template <typename T>
+__global__ void k_pack_vecs(SetupArgs a) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    const T* g = (const T*)a.g_in;
+    const T* l = (const T*)a.l_in;
+    const T* u = (const T*)a.u_in;
+    for (size_t i = tid; i < (size_t)a.B * a.n; i += nth) ((T*)a.g)[i] = g[i];
+    for (size_t i = tid; i < (size_t)a.B * a.m; i += nth) {
+        T li = l[i], ui = u[i];
+        ((T*)a.l)[i] = li;
+        ((T*)a.u)[i] = ui;
+        ((T*)a.c)[i] = ((ui - li) <= (T)a.eq_tol) ? T(1e3) : T(1);   // NaN (inf-inf) compares false
+    }
+}
+
+hipError_t rqp_launch_pack(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    dim3 grid(64, h->nmat);
+    if (h->esz == 4) {
+        k_pack_mats<float><<<grid, 256, 0, s>>>(a);
+        k_pack_vecs<float><<<256, 256, 0, s>>>(a);
+    } else {
+        k_pack_mats<double><<<grid, 256, 0, s>>>(a);
+        k_pack_vecs<double><<<256, 256, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+// update(g,l,u): reluqpth.py:159-183.  c (and K) are NOT re-derived: the reference keeps the
+// matrices built at setup when l/u change (W_ks untouched, :171-174).
+template <typename T>
+__global__ void k_vec_update(int B, int n, int m, const T* g, const T* l, const T* u, T* gd, T* ld, T* ud) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    if (g) for (size_t i = tid; i < (size_t)B * n; i += nth) gd[i] = g[i];
+    if (l) for (size_t i = tid; i < (size_t)B * m; i += nth) ld[i] = l[i];
+    if (u) for (size_t i = tid; i < (size_t)B * m; i += nth) ud[i] = u[i];
+}
+
+hipError_t rqp_launch_vec_update(const rqp_handle* h, const void* g, const void* l, const void* u, hipStream_t s) {
+    if (h->esz == 4)
+        k_vec_update<float><<<256, 256, 0, s>>>(h->B, h->n, h->m, (const float*)g, (const float*)l, (const float*)u,
+                                                  (float*)h->g, (float*)h->l, (float*)h->u);
+    else
+        k_vec_update<double><<<256, 256, 0, s>>>(h->B, h->n, h->m, (const double*)g, (const double*)l,
+                                                   (const double*)u, (double*)h->g, (double*)h->l, (double*)h->u);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ gram
+// G[r][c] = sum_k c_k A[k][r] A[k][c] in float64.  One workgroup = one 64x64 output tile of
+// one matrix; 16x16 threads, 4x4 register tile each; A staged through LDS 16 rows at a time.
+#define GR_T 64
+#define GR_K 16
+template <typename T>
+__global__ void __launch_bounds__(256) k_gram(SetupArgs a) {
+    __shared__ double sR[GR_K][GR_T + 1];
+    __shared__ double sC[GR_K][GR_T + 1];
+    const int mat = blockIdx.z;
+    const int r0 = blockIdx.y * GR_T, c0 = blockIdx.x * GR_T;
+    const T* A = (const T*)a.A + (size_t)mat * a.m * a.ldn;
+    const T* cv = (const T*)a.c + (size_t)mat * a.m;   // shared mats: instance 0's pattern (mat = 0)
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < a.m; k0 += GR_K) {
+        for (int i = threadIdx.x; i < GR_K * GR_T; i += 256) {
+            int kk = i / GR_T, cc = i % GR_T;
+            int k = k0 + kk;
+            double vr = 0.0, vc = 0.0;
+            if (k < a.m) {
+                if (r0 + cc < a.n) vr = (double)A[(size_t)k * a.ldn + r0 + cc] * (double)cv[k];
+                if (c0 + cc < a.n) vc = (double)A[(size_t)k * a.ldn + c0 + cc];
+            }
+            sR[kk][cc] = vr;
+            sC[kk][cc] = vc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GR_K; ++kk) {
+            double rv[4], cvv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = sR[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cvv[j] = sC[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(rv[i], cvv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    double* G = a.G + (size_t)mat * a.n * a.n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r = r0 + ty * 4 + i, c = c0 + tx * 4 + j;
+            if (r < a.n && c < a.n) G[(size_t)r * a.n + c] = acc[i][j];
+        }
+}
+
+hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    int t = (h->n + GR_T - 1) / GR_T;
+    dim3 grid(t, t, h->nmat);
+    if (h->esz == 4)
+        k_gram<float><<<grid, 256, 0, s>>>(a);
+    else
+        k_gram<double><<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- factor
+// One workgroup per (matrix, rho index): M = sym(H) + sigma I + rho_j G, inverted in place by
+// Gauss-Jordan (SPD, no pivoting), float64.  LDS_MODE: M lives in LDS (n*n*8 B <= ~150 KB);
+// otherwise in a global scratch slab (L2-resident).  Output K_j in T, padded rows zeroed.
+template <typename T, bool LDS_MODE>
+__global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = a.n;
+    const int mat = blockIdx.x / a.nrho, j = blockIdx.x % a.nrho;
+    double* colb = (double*)smem_raw;            // [n]   column k before the sweep
+    double* rowb = colb + n;                     // [n]   scaled pivot row
+    double* M = LDS_MODE ? (rowb + n) : (a.fscratch + (size_t)blockIdx.x * n * n);
+    const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
+    const double* G = a.G + (size_t)mat * n * n;
+    const double rho = a.rhos[j];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += 256) {
+        int r = i / n, c = i % n;
+        double hs = 0.5 * ((double)Ht[(size_t)r * a.ldn + c] + (double)Ht[(size_t)c * a.ldn + r]);
+        M[i] = hs + (r == c ? a.sigma : 0.0) + rho * G[i];
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double p = 1.0 / M[(size_t)k * n + k];
+        for (int i = tid; i < n; i += 256) {
+            colb[i] = M[(size_t)i * n + k];
+            rowb[i] = (i == k) ? p : M[(size_t)k * n + i] * p;
+        }
+        __syncthreads();
+        for (int i = tid; i < n * n; i += 256) {
+            int r = i / n, c = i % n;
+            double v;
+            if (r == k)
+                v = rowb[c];
+            else if (c == k)
+                v = -colb[r] * p;
+            else
+                v = M[i] - colb[r] * rowb[c];
+            M[i] = v;
+        }
+        __syncthreads();
+    }
+    T* K = (T*)a.K + ((size_t)mat * a.nrho + j) * n * a.ldn;
+    for (int i = tid; i < n * a.ldn; i += 256) {
+        int r = i / a.ldn, c = i % a.ldn;
+        // symmetrise the rounded result so that column-oriented products see one matrix
+        K[i] = (c < n) ? (T)(0.5 * (M[(size_t)r * n + c] + M[(size_t)c * n + r])) : T(0);
+    }
+}
+
+hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    const int n = h->n;
+    const size_t lds_need = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);
+    const bool lds_mode = lds_need <= 160 * 1024 - 512;
+    const int grid = h->nmat * h->nrho;
+    hipError_t e;
+    if (lds_mode) {
+        if (h->esz == 4) {
+            e = hipFuncSetAttribute((const void*)k_factor<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_need);
+            if (e != hipSuccess) return e;
+            k_factor<float, true><<<grid, 256, lds_need, s>>>(a);
+        } else {
+            e = hipFuncSetAttribute((const void*)k_factor<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_need);
+            if (e != hipSuccess) return e;
+            k_factor<double, true><<<grid, 256, lds_need, s>>>(a);
+        }
+    } else {
+        const size_t small = 2 * (size_t)n * sizeof(double);
+        if (h->esz == 4)
+            k_factor<float, false><<<grid, 256, small, s>>>(a);
+        else
+            k_factor<double, false><<<grid, 256, small, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------- state movers
+template <typename T>
+__global__ void k_state_set(int B, int n, int m, const T* x, const T* z, const T* lam, double* xs, double* zs,
+                            double* ls, int set_rho, int rho_ind, int32_t* ri) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    if (x) for (size_t i = tid; i < (size_t)B * n; i += nth) xs[i] = (double)x[i];
+    if (z) for (size_t i = tid; i < (size_t)B * m; i += nth) zs[i] = (double)z[i];
+    if (lam) for (size_t i = tid; i < (size_t)B * m; i += nth) ls[i] = (double)lam[i];
+    if (set_rho) for (int i = tid; i < B; i += nth) ri[i] = rho_ind;
+}
+
+hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* z, const void* lam, int set_rho,
+                                int rho_ind, hipStream_t s) {
+    if (h->esz == 4)
+        k_state_set<float><<<256, 256, 0, s>>>(h->B, h->n, h->m, (const float*)x, (const float*)z, (const float*)lam,
+                                                 h->x, h->z, h->lam, set_rho, rho_ind, h->rho_ind);
+    else
+        k_state_set<double><<<256, 256, 0, s>>>(h->B, h->n, h->m, (const double*)x, (const double*)z,
+                                                  (const double*)lam, h->x, h->z, h->lam, set_rho, rho_ind, h->rho_ind);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_state_get(int B, int n, int m, T* x, T* z, T* lam, const double* xs, const double* zs,
+                            const double* ls, int32_t* ri_out, const int32_t* ri) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    if (x) for (size_t i = tid; i < (size_t)B * n; i += nth) x[i] = (T)xs[i];
+    if (z) for (size_t i = tid; i < (size_t)B * m; i += nth) z[i] = (T)zs[i];
+    if (lam) for (size_t i = tid; i < (size_t)B * m; i += nth) lam[i] = (T)ls[i];
+    if (ri_out) for (int i = tid; i < B; i += nth) ri_out[i] = ri[i];
+}
+
+hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s) {
+    if (h->esz == 4)
+        k_state_get<float><<<256, 256, 0, s>>>(h->B, h->n, h->m, (float*)x, (float*)z, (float*)lam, h->x, h->z, h->lam,
+                                                 rho_ind, h->rho_ind);
+    else
+        k_state_get<double><<<256, 256, 0, s>>>(h->B, h->n, h->m, (double*)x, (double*)z, (double*)lam, h->x, h->z,
+                                                  h->lam, rho_ind, h->rho_ind);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_get_K(int n, int ldn, const T* K, T* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += gridDim.x * blockDim.x)
+        out[i] = K[(size_t)(i / n) * ldn + (i % n)];
+}
+
+hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s) {
+    const size_t off = ((size_t)(h->dims.shared_mats ? 0 : b) * h->nrho + j) * h->n * h->ldn;
+    if (h->esz == 4)
+        k_get_K<float><<<64, 256, 0, s>>>(h->n, h->ldn, (const float*)h->K + off, (float*)out);
+    else
+        k_get_K<double><<<64, 256, 0, s>>>(h->n, h->ldn, (const double*)h->K + off, (double*)out);
+    return hipGetLastError();
+}

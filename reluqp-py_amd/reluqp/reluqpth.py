@@ -1,0 +1,385 @@
+"""OSQP-style solver API: drop-in for the reference's ``reluqp.reluqpth``
+(ReLU-QP-py/reluqp/reluqpth.py:92-333) on MI355X.
+
+    import reluqp.reluqpth as reluqpth
+    model = reluqpth.ReLU_QP()
+    model.setup(H, g, A, l, u, eps_abs=1e-4)
+    results = model.solve()          # results.x, results.z, results.info.{iter,status,...}
+    model.update(g=g2, l=l2, u=u2); results = model.solve()     # warm-started
+
+Same method names, keyword arguments, defaults and Results/Info fields as the
+reference.  Host code here is plumbing only: tensors in HBM, raw pointers and the
+current HIP stream handed to librqp_hip.so (include/rqp_abi.h).  All arithmetic of
+setup()/solve()/update() runs in hand-written gfx950 kernels; there is no torch or
+CPU fallback and the calls raise if the library or a GPU is missing.
+
+Extensions: a leading batch dimension on g, l, u (and
+optionally on H, A -- un-batched H, A are shared by the batch), ``precision``
+honoured (float32 / float64), ``eq_tol`` settable, ``Results.y`` (dual), torch or
+numpy accepted everywhere, per-instance info tensors in batch mode.
+
+Reference quirks are handled as listed in SURVEY.md Appendix B (DESIGN.md has the
+table): Q1/Q2/Q3/Q6/Q8/Q9/Q11/Q13/Q14 fixed, Q4/Q5/Q10/Q15/Q16/Q17 replicated.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from reluqp import _cabi
+from reluqp.classes import QP, Info, Results, Settings, _as_tensor, _default_device
+
+_CHANGEABLE = ("max_iter", "eps_abs", "verbose", "check_interval")
+_FROZEN = ("rho", "rho_min", "rho_max", "sigma", "adaptive_rho", "adaptive_rho_interval",
+           "adaptive_rho_tolerance")
+
+
+class _Layers(object):
+    """Stand-in for the reference's ``ReLU_QP.layers`` (class ReLU_Layer, reluqpth.py:8-89):
+    exposes the rho ladder and the per-rho KKT inverses; W is never materialised."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.rhos = owner._rhos
+
+    def K(self, rho_ind, instance=0):
+        """K_j = (H + sigma I + A' diag(rho_j c) A)^-1 of one instance (reluqpth.py:56)."""
+        o = self._o
+        out = torch.empty(o.QP.nx, o.QP.nx, device=o.settings.device, dtype=o.settings.precision)
+        lib = _cabi.load()
+        _cabi.check(o._h, lib.rqp_get_K(o._h, int(instance), int(rho_ind), _cabi.ptr(out), o._stream()), "rqp_get_K")
+        torch.cuda.current_stream(o.settings.device).synchronize()
+        return out
+
+
+class ReLU_QP(object):
+    def __init__(self):
+        super().__init__()
+        self.info = Info()
+        self.results = Results(info=self.info)
+        self._h = None
+        self.settings = None
+        self.QP = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.settings.device).cuda_stream)
+
+    def _events(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def _csettings(self):
+        s = self.settings
+        return _cabi.CSettings(rho=s.rho, rho_min=s.rho_min, rho_max=s.rho_max, sigma=s.sigma,
+                               adaptive_rho_tolerance=s.adaptive_rho_tolerance, eps_abs=s.eps_abs,
+                               eq_tol=s.eq_tol, adaptive_rho=int(bool(s.adaptive_rho)),
+                               max_iter=int(s.max_iter), check_interval=int(s.check_interval),
+                               warm_starting=int(bool(s.warm_starting)))
+
+    def _to_dev(self, a, shape, name):
+        t = _as_tensor(a).to(device=self.settings.device, dtype=self.settings.precision).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+        return t
+
+    def __del__(self):
+        self._destroy()
+
+    def _destroy(self):
+        if getattr(self, "_h", None):
+            try:
+                _cabi.load().rqp_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    # -------------------------------------------------------------------- setup
+    def setup(self, H, g, A, l, u,
+              verbose=False,
+              warm_starting=True,
+              scaling=False,  # accepted, unused -- as in the reference (Q12)
+              rho=0.1,
+              rho_min=1e-6,
+              rho_max=1e6,
+              sigma=1e-6,
+              adaptive_rho=True,
+              adaptive_rho_interval=1,
+              adaptive_rho_tolerance=5,
+              max_iter=4000,
+              eps_abs=1e-3,
+              check_interval=25,
+              device=None,
+              precision=torch.float64,
+              eq_tol=1e-6):
+        """
+        Setup ReLU-QP solver problem of the form
+
+        minimize     1/2 x' * H * x + g' * x
+        subject to   l <= A * x <= u
+
+        solver settings can be specified as additional keyword arguments
+        (reference reluqpth.py:102-157).  g, l, u may carry a leading batch
+        dimension; H and A then either carry it too or are shared.
+        """
+        device = _default_device() if device is None else torch.device(device)
+        if precision not in (torch.float32, torch.float64):
+            raise ValueError("precision must be torch.float32 or torch.float64")
+        if device.type != "cuda":
+            raise _cabi.RqpUnavailable(
+                "ReLU_QP needs a HIP device (got device=%s); the MI355X build has no CPU path" % device)
+        lib = _cabi.load()
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._destroy()
+
+        self.settings = Settings(verbose=verbose, warm_starting=warm_starting, scaling=scaling, rho=rho,
+                                 rho_min=rho_min, rho_max=rho_max, sigma=sigma, adaptive_rho=adaptive_rho,
+                                 adaptive_rho_interval=adaptive_rho_interval,
+                                 adaptive_rho_tolerance=adaptive_rho_tolerance, max_iter=max_iter,
+                                 eps_abs=eps_abs, eq_tol=eq_tol, check_interval=check_interval,
+                                 device=device, precision=precision)
+        with torch.cuda.device(device):
+            start, end = self._events()
+            start.record()
+            self.QP = QP(H, g, A, l, u, device=device, precision=precision)
+            qp = self.QP
+            dims = _cabi.Dims(n=qp.nx, m=qp.nc, batch=qp.batch, shared_mats=int(qp.shared_mats),
+                              dtype=_cabi.RQP_F32 if precision == torch.float32 else _cabi.RQP_F64, reserved=0)
+            cs = self._csettings()
+            h = ctypes.c_void_p()
+            _cabi.check(None, lib.rqp_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(cs), device.index),
+                        "rqp_create")
+            self._h = h
+            _cabi.check(h, lib.rqp_setup(h, _cabi.ptr(qp.H), _cabi.ptr(qp.g), _cabi.ptr(qp.A), _cabi.ptr(qp.l),
+                                         _cabi.ptr(qp.u), self._stream()), "rqp_setup")
+            cnt = ctypes.c_int32()
+            _cabi.check(h, lib.rqp_get_rhos(h, None, 0, ctypes.byref(cnt)), "rqp_get_rhos")
+            buf = (ctypes.c_double * cnt.value)()
+            _cabi.check(h, lib.rqp_get_rhos(h, buf, cnt.value, ctypes.byref(cnt)), "rqp_get_rhos")
+            self._rhos = torch.tensor(list(buf), dtype=precision, device=device)
+            self.layers = _Layers(self)
+            self.rho_ind = int(np.argmin(np.abs(np.array(list(buf)) - self.settings.rho)))
+            end.record()
+            end.synchronize()
+            self.results.info.setup_time = start.elapsed_time(end) / 1000.0
+        self.kernel = lib.rqp_kernel_name(h).decode()
+        return None
+
+    # ------------------------------------------------------------------- update
+    def update(self, g=None, l=None, u=None, Hx=None, Ax=None):
+        """
+        Update ReLU-QP problem arguments (reference reluqpth.py:159-183; numpy or torch, Q9)
+        """
+        self._need_setup()
+        # assert that matrices cannot be changed for now (reluqpth.py:177)
+        assert Hx is None and Ax is None, "updating Hx and Ax is not supported yet"
+        lib = _cabi.load()
+        qp = self.QP
+        lead = (qp.batch,) if qp.batched else ()
+        with torch.cuda.device(self.settings.device):
+            start, end = self._events()
+            start.record()
+            if g is not None:
+                qp.g = self._to_dev(g, lead + (qp.nx,), "g")
+            if l is not None:
+                qp.l = self._to_dev(l, lead + (qp.nc,), "l")
+            if u is not None:
+                qp.u = self._to_dev(u, lead + (qp.nc,), "u")
+            _cabi.check(self._h, lib.rqp_update(self._h, _cabi.ptr(qp.g if g is not None else None),
+                                                _cabi.ptr(qp.l if l is not None else None),
+                                                _cabi.ptr(qp.u if u is not None else None), self._stream()),
+                        "rqp_update")
+            end.record()
+            end.synchronize()
+            self.results.info.update_time = start.elapsed_time(end) / 1000.0
+        return None
+
+    def update_settings(self, **kwargs):
+        """
+        Update ReLU-QP solver settings
+
+        It is possible to change: 'max_iter', 'eps_abs', 'verbose', 'check_interval'
+        (reference reluqpth.py:185-199; the whitelist typo "eps_ab" is tolerated, Q8)
+        """
+        self._need_setup()
+        for key, value in kwargs.items():
+            if key == "eps_ab":
+                key = "eps_abs"
+            if key in _CHANGEABLE:
+                setattr(self.settings, key, value)
+            elif key in _FROZEN:
+                raise ValueError("Cannot change {} after setup".format(key))
+            else:
+                raise ValueError("Invalid setting: {}".format(key))
+        cs = self._csettings()
+        _cabi.check(self._h, _cabi.load().rqp_update_settings(self._h, ctypes.byref(cs)), "rqp_update_settings")
+
+    # -------------------------------------------------------------------- solve
+    def solve(self):
+        """
+        Solve QP Problem (reference reluqpth.py:201-249 + update_results :278-305):
+        one kernel launch for the whole batch, synchronised before returning.
+        """
+        self._need_setup()
+        lib = _cabi.load()
+        st, qp = self.settings, self.QP
+        dev, B, n, m = st.device, qp.batch, qp.nx, qp.nc
+        with torch.cuda.device(dev):
+            start, end = self._events()
+            start.record()
+            x = torch.empty(B, n, device=dev, dtype=st.precision)
+            z = torch.empty(B, m, device=dev, dtype=st.precision)
+            lam = torch.empty(B, m, device=dev, dtype=st.precision)
+            ints = torch.empty(3, B, device=dev, dtype=torch.int32)
+            dbls = torch.empty(4, B, device=dev, dtype=torch.float64)
+            trace, cap = None, 0
+            if st.verbose or getattr(self, "collect_trace", False):
+                cap = max(1, st.max_iter // st.check_interval)
+                trace = torch.full((B, cap, 4), float("nan"), device=dev, dtype=torch.float64)
+            ci = _cabi.CInfo(iter=ints[0].data_ptr(), status=ints[1].data_ptr(), rho_ind=ints[2].data_ptr(),
+                             pri_res=dbls[0].data_ptr(), dua_res=dbls[1].data_ptr(),
+                             rho_estimate=dbls[2].data_ptr(), obj_val=dbls[3].data_ptr(),
+                             trace=trace.data_ptr() if trace is not None else None, trace_cap=cap, reserved=0)
+            _cabi.check(self._h, lib.rqp_solve(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
+                                               ctypes.byref(ci), self._stream()), "rqp_solve")
+            end.record()
+            end.synchronize()
+            run_time = start.elapsed_time(end) / 1000.0
+        self.last_trace = trace      # [batch][checks][pri, dua, rho_estimate, rho_ind before the move]
+        if st.verbose:
+            self._print_trace(trace)
+        self._update_results(x, z, lam, ints, dbls, run_time)
+        return self.results
+
+    def _print_trace(self, trace):
+        tr = trace[0].cpu().numpy()      # instance 0, same line format as reluqpth.py:230
+        for c in range(tr.shape[0]):
+            if np.isnan(tr[c, 3]):
+                break
+            print('Iter: {}, rho: {:.2e}, res_p: {:.2e}, res_d: {:.2e}'.format(
+                (c + 1) * self.settings.check_interval, tr[c, 2], tr[c, 0], tr[c, 1]))
+
+    def _update_results(self, x, z, lam, ints, dbls, run_time):
+        """Update results and info (reference reluqpth.py:278-305)."""
+        qp, prec = self.QP, self.settings.precision
+        info = self.results.info
+        if qp.batched:
+            self.results.x, self.results.z, self.results.y = x, z, lam
+            info.iter = ints[0]
+            info.status_code = ints[1]
+            info.status = [_cabi.STATUS_STR[int(c)] for c in ints[1].cpu().tolist()]
+            info.rho_ind = ints[2]
+            info.pri_res, info.dua_res = dbls[0].to(prec), dbls[1].to(prec)
+            info.rho_estimate, info.obj_val = dbls[2].to(prec), dbls[3].to(prec)
+            self.rho_ind = ints[2]
+        else:
+            self.results.x, self.results.z, self.results.y = x[0], z[0], lam[0]
+            ih = ints[:, 0].cpu().tolist()
+            info.iter = int(ih[0])
+            info.status_code = int(ih[1])
+            info.status = _cabi.STATUS_STR[int(ih[1])]
+            info.rho_ind = int(ih[2])
+            info.pri_res, info.dua_res = dbls[0, 0].to(prec), dbls[1, 0].to(prec)
+            info.rho_estimate, info.obj_val = dbls[2, 0].to(prec), dbls[3, 0].to(prec)
+            self.rho_ind = int(ih[2]) if self.settings.warm_starting else self._rho_ind0()
+        self.results.lam = self.results.y
+        self.x, self.z, self.lam = self.results.x, self.results.z, self.results.y
+        info.run_time = run_time
+        info.solve_time = info.update_time + run_time
+
+    def _rho_ind0(self):
+        return int(np.argmin(np.abs(self._rhos.cpu().numpy() - self.settings.rho)))
+
+    # --------------------------------------------------------------- warm start
+    def warm_start(self, x=None, z=None, lam=None, rho=None):
+        """
+        Warm start primal or dual variables, lagrange multipliers, and rho
+        (reference reluqpth.py:251-276; values are written into the iterate, Q6 fixed)
+        """
+        self._need_setup()
+        qp = self.QP
+        lead = (qp.batch,) if qp.batched else ()
+        xt = None if x is None else self._to_dev(x, lead + (qp.nx,), "x")
+        zt = None if z is None else self._to_dev(z, lead + (qp.nc,), "z")
+        lt = None if lam is None else self._to_dev(lam, lead + (qp.nc,), "lam")
+        with torch.cuda.device(self.settings.device):
+            _cabi.check(self._h, _cabi.load().rqp_warm_start(
+                self._h, _cabi.ptr(xt), _cabi.ptr(zt), _cabi.ptr(lt), int(rho is not None),
+                float(rho) if rho is not None else 0.0, self._stream()), "rqp_warm_start")
+            torch.cuda.current_stream(self.settings.device).synchronize()
+        if rho is not None:
+            self.rho_ind = int(np.argmin(np.abs(self._rhos.cpu().numpy() - rho)))
+        return None
+
+    def clear_primal_dual(self):
+        """
+        Clear primal and dual variables and reset rho index (reference reluqpth.py:324-333)
+        """
+        self._need_setup()
+        with torch.cuda.device(self.settings.device):
+            _cabi.check(self._h, _cabi.load().rqp_clear_primal_dual(self._h, self._stream()),
+                        "rqp_clear_primal_dual")
+        self.rho_ind = self._rho_ind0()
+        return None
+
+    # ---------------------------------------------------- test / inspection hooks
+    def iterate(self, k):
+        """k plain ADMM iterations (ReLU_Layer.forward, reluqpth.py:80-89), no checks."""
+        self._need_setup()
+        with torch.cuda.device(self.settings.device):
+            _cabi.check(self._h, _cabi.load().rqp_iterate(self._h, int(k), self._stream()), "rqp_iterate")
+        return self.get_state()[0]
+
+    def get_state(self):
+        """(output, rho_ind): ``output`` = [x; z; lam] as the reference's ``ReLU_QP.output``."""
+        self._need_setup()
+        st, qp = self.settings, self.QP
+        B, n, m = qp.batch, qp.nx, qp.nc
+        with torch.cuda.device(st.device):
+            x = torch.empty(B, n, device=st.device, dtype=st.precision)
+            z = torch.empty(B, m, device=st.device, dtype=st.precision)
+            lam = torch.empty(B, m, device=st.device, dtype=st.precision)
+            ri = torch.empty(B, device=st.device, dtype=torch.int32)
+            _cabi.check(self._h, _cabi.load().rqp_get_state(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
+                                                            _cabi.ptr(ri), self._stream()), "rqp_get_state")
+            torch.cuda.current_stream(st.device).synchronize()
+        out = torch.cat([x, z, lam], dim=1)
+        return (out, ri) if qp.batched else (out[0], int(ri[0]))
+
+    @property
+    def output(self):
+        return self.get_state()[0]
+
+    def compute_residuals(self, rho):
+        """(primal_res, dual_res, rho_estimate, obj) of the current state for a carried
+        estimate ``rho`` (reference compute_residuals/compute_J, reluqpth.py:307-322)."""
+        self._need_setup()
+        st, B = self.settings, self.QP.batch
+        with torch.cuda.device(st.device):
+            out = torch.empty(4, B, device=st.device, dtype=torch.float64)
+            _cabi.check(self._h, _cabi.load().rqp_compute_residuals(
+                self._h, float(rho), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                self._stream()), "rqp_compute_residuals")
+            torch.cuda.current_stream(st.device).synchronize()
+        if self.QP.batched:
+            return out[0], out[1], out[2], out[3]
+        return out[0, 0], out[1, 0], out[2, 0], out[3, 0]
+
+    def _need_setup(self):
+        if self._h is None:
+            raise RuntimeError("ReLU_QP.setup() must be called first")
+
+
+if __name__ == "__main__":
+    # the reference's inline known-answer test (reluqpth.py:338-367)
+    H = torch.tensor([[6, 2, 1], [2, 5, 2], [1, 2, 4.0]], dtype=torch.double)
+    g = torch.tensor([-8.0, -3, -3], dtype=torch.double)
+    A = torch.tensor([[1, 0, 1], [0, 1, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.double)
+    l = torch.tensor([3.0, 0, -10.0, -10, -10], dtype=torch.double)
+    u = torch.tensor([3.0, 0, torch.inf, torch.inf, torch.inf], dtype=torch.double)
+    qp = ReLU_QP()
+    qp.setup(H=H, g=g, A=A, l=l, u=u)
+    results = qp.solve()
+    assert torch.allclose(results.x.cpu(), torch.tensor([2.0, -1, 1], dtype=torch.float64))
+    print("Test passed!")
+    print(results.x, results.info.solve_time, results.info.setup_time, results.info.iter, results.info.status)

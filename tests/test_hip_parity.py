@@ -1,0 +1,369 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C-ABI (reluqp.reluqpth.ReLU_QP -> librqp_hip.so), against
+
+  * the committed golden fixtures, i.e. outputs of the REFERENCE itself (fp64), and
+  * the oracle (oracle/reluqp_oracle.py) on seeded inputs.
+
+Stated tolerances
+  float64 kernels: x, z, state within 1e-7 relative / 1e-8 absolute of the reference
+      (different association of the same recurrence; K by Gauss-Jordan vs LAPACK).
+  float32 kernels: same iteration counts and rho-index trajectory on the fixtures;
+      x, z within 2e-5 * max|x| of the float64 reference (observed ~1e-6), residual
+      traces within 1e-3 relative / 1e-4 absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reluqp_oracle as O
+from reluqp import utils
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-7, atol=1e-8)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _model(H, g, A, l, u, precision=torch.float64, **kw):
+    import reluqp.reluqpth as reluqpth
+    m = reluqpth.ReLU_QP()
+    m.collect_trace = True
+    m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
+    return m
+
+
+def _np(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _trace(model, b=0):
+    tr = _np(model.last_trace[b])
+    return tr[~np.isnan(tr[:, 3])]
+
+
+def _qp(gold, p=""):
+    return [gold[p + k] for k in ("H", "g", "A", "l", "u")]
+
+
+def _check_vs_gold(gold, p, model, res, xtol, check_rho=True, res_rtol=1e-4, res_atol=1e-6):
+    assert res.info.iter == int(gold[p + "iter"])
+    assert res.info.status == str(gold[p + "status"])
+    scale = max(1.0, np.abs(gold[p + "state"]).max())
+    np.testing.assert_allclose(_np(res.x), gold[p + "x"], rtol=0, atol=xtol * scale)
+    np.testing.assert_allclose(_np(res.z), gold[p + "z"], rtol=0, atol=xtol * scale)
+    state, ri = model.get_state()
+    np.testing.assert_allclose(_np(state), gold[p + "state"], rtol=0, atol=xtol * scale * 10)
+    np.testing.assert_allclose(float(res.info.obj_val), float(gold[p + "obj_val"]), rtol=1e-4, atol=xtol * 100)
+    if not check_rho:
+        return
+    assert ri == int(gold[p + "rho_ind_final"])
+    tr, gt = _trace(model), gold[p + "trace"]
+    assert tr.shape == gt.shape
+    assert np.array_equal(tr[:, 3], gt[:, 3])                      # rho-index trajectory: exact
+    np.testing.assert_allclose(tr[:, :2], gt[:, :2], rtol=res_rtol, atol=res_atol)
+    ok = ~np.isnan(gt[:, 2]) & (gt[:, 0] > 1e-6) & (gt[:, 1] > 1e-6)
+    np.testing.assert_allclose(tr[ok, 2], gt[ok, 2], rtol=2e-2)
+
+
+PREC = [(torch.float64, 1e-8, 1e-5, 1e-6), (torch.float32, 2e-5, 1e-3, 1e-4)]
+
+
+# ------------------------------------------------------------------------ G1 builtin
+def test_g1_ladder_and_kernel_loaded(golden):
+    g = golden("g1_builtin.npz")
+    m = _model(*_qp(g))
+    assert np.array_equal(_np(m.layers.rhos), g["rhos"])
+    assert m.rho_ind == int(g["rho_ind0"]) == 7
+    assert m.kernel in ("generic", "resident")
+    m2 = _model(*_qp(g), adaptive_rho=False)
+    assert np.array_equal(_np(m2.layers.rhos), g["rhos_noadapt"])
+    m3 = _model(*_qp(g), rho=0.4, rho_min=1e-3, rho_max=1e3, adaptive_rho_tolerance=3)
+    assert np.array_equal(_np(m3.layers.rhos), g["rhos_alt"])
+    assert m3.rho_ind == int(g["rho_ind0_alt"])
+
+
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+def test_g1_iterates(golden, prec, xtol, rr, ra):
+    g = golden("g1_builtin.npz")
+    for k, key in ((1, "state_k1"), (2, "state_k2"), (25, "state_k25")):
+        m = _model(*_qp(g), precision=prec)
+        s = m.iterate(k)
+        np.testing.assert_allclose(_np(s), g[key], rtol=0, atol=xtol * 10 * max(1, np.abs(g[key]).max()))
+    # k iterations in two calls == one call (state round-trips through HBM in float64)
+    m = _model(*_qp(g), precision=prec)
+    m.iterate(10)
+    s = m.iterate(15)
+    np.testing.assert_allclose(_np(s), g["state_k25"], rtol=0, atol=xtol * 10 * 5)
+
+
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+def test_g1_solve_warm_cold_maxiter(golden, prec, xtol, rr, ra):
+    g = golden("g1_builtin.npz")
+    m = _model(*_qp(g), precision=prec)
+    res = m.solve()
+    # converges to rounding noise at k=25: the last rho estimate is a ratio of noise, skip it
+    _check_vs_gold(g, "", m, res, xtol, check_rho=False)
+    assert torch.allclose(res.x.cpu().double(), torch.tensor([2.0, -1, 1], dtype=torch.float64),
+                          atol=1e-8 if prec == torch.float64 else 2e-5)            # reluqpth.py:360
+    res2 = m.solve()                                                               # warm re-solve
+    _check_vs_gold(g, "warm_", m, res2, xtol, check_rho=False)
+    # warm_starting=False clears the state and resets the index (reluqpth.py:304-305, :324-333)
+    mc = _model(*_qp(g), precision=prec, warm_starting=False)
+    rc = mc.solve()
+    assert rc.info.iter == int(g["cold_iter"])
+    st, ri = mc.get_state()
+    assert np.array_equal(_np(st), g["cold_state_after"]) and ri == int(g["cold_rho_ind_after"])
+    # max_iters_reached, max_iter not a multiple of check_interval (Q11 fixed: fresh slices)
+    mm = _model(*_qp(g), precision=prec, max_iter=10)
+    rm = mm.solve()
+    assert rm.info.status == "max_iters_reached" and rm.info.iter == 10
+    st, _ = mm.get_state()
+    np.testing.assert_allclose(_np(st), g["mi10_state"], rtol=0, atol=xtol * 100)
+    np.testing.assert_allclose(_np(rm.x), g["mi10_state"][:3], rtol=0, atol=xtol * 100)
+    assert float(rm.info.pri_res) > 0 and float(rm.info.dua_res) > 0
+
+
+def test_g1_tight_fp64(golden):
+    g = golden("g1_builtin.npz")
+    m = _model(*_qp(g), eps_abs=1e-8)
+    res = m.solve()
+    _check_vs_gold(g, "tight_", m, res, 1e-8, check_rho=False)
+
+
+# ------------------------------------------------------------- G2 reference generator
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+@pytest.mark.parametrize("seed", range(5))
+def test_g2_compat(golden, seed, prec, xtol, rr, ra):
+    g = golden("g2_randqp_compat.npz")
+    p = "s%d_" % seed
+    m = _model(*_qp(g, p), precision=prec)
+    res = m.solve()
+    _check_vs_gold(g, p, m, res, xtol, res_rtol=rr, res_atol=ra)
+
+
+# ----------------------------------------------------------------- G3: C1 (n=10, m=20)
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+@pytest.mark.parametrize("seed", range(3))
+def test_g3_c1(golden, seed, prec, xtol, rr, ra):
+    g = golden("g3_c1_feasible.npz")
+    p = "s%d_" % seed
+    m = _model(*_qp(g, p), precision=prec)
+    res = m.solve()
+    _check_vs_gold(g, p, m, res, xtol, res_rtol=rr, res_atol=ra)
+    if prec == torch.float64:
+        mt = _model(*_qp(g, p), eps_abs=1e-9, max_iter=20000)
+        rt = mt.solve()
+        assert rt.info.status == "solved" and abs(rt.info.iter - int(g[p + "tight_iter"])) <= 25
+        np.testing.assert_allclose(_np(rt.x), g[p + "x_planted"], atol=1e-8)
+
+
+# ----------------------------------------------- G4: C2 (n=100, m=300) and C4 (32, 64)
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+@pytest.mark.parametrize("seed", range(3))
+def test_g4_c2(golden, seed, prec, xtol, rr, ra):
+    g = golden("g4_c2_feasible.npz")
+    p = "s%d_" % seed
+    H, gg, A, l, u, xs = utils.rand_qp(nx=100, n_eq=25, n_ineq=275, seed=seed, feasible=True)
+    m = _model(H, gg, A, l, u, precision=prec)
+    res = m.solve()
+    _check_vs_gold(g, p, m, res, xtol, res_rtol=rr, res_atol=ra)
+    if seed == 1 and prec == torch.float64:
+        mt = _model(H, gg, A, l, u, eps_abs=1e-6)
+        rt = mt.solve()
+        _check_vs_gold(g, p + "e6_", mt, rt, 1e-8, res_rtol=1e-3, res_atol=1e-6)
+
+
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+@pytest.mark.parametrize("seed", range(3))
+def test_g4_c4_shape(golden, seed, prec, xtol, rr, ra):
+    g = golden("g4_c2_feasible.npz")
+    p = "c4s%d_" % seed
+    H, gg, A, l, u, xs = utils.rand_qp(nx=32, n_eq=8, n_ineq=56, seed=seed, feasible=True)
+    m = _model(H, gg, A, l, u, precision=prec)
+    res = m.solve()
+    _check_vs_gold(g, p, m, res, xtol, res_rtol=rr, res_atol=ra)
+
+
+# -------------------------------------------------------------------- G5: update()
+@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
+def test_g5_update(golden, prec, xtol, rr, ra):
+    g1, g = golden("g1_builtin.npz"), golden("g5_update.npz")
+    m = _model(*_qp(g1), precision=prec)
+    m.solve()
+    m.update(g=g["g_new"])                                         # numpy accepted (reference)
+    res = m.solve()
+    _check_vs_gold(g, "upd_g_", m, res, xtol, check_rho=False)
+    m.update(l=torch.from_numpy(g["l_new"]), u=torch.from_numpy(g["u_new"]))   # torch accepted (Q9)
+    res = m.solve()
+    _check_vs_gold(g, "upd_lu_", m, res, xtol, check_rho=False)
+    assert res.info.solve_time >= res.info.run_time > 0
+    with pytest.raises(AssertionError):
+        m.update(Hx=np.eye(3))                                     # reluqpth.py:177
+
+
+# --------------------------------------------- G6: compute_residuals / compute_J
+@pytest.mark.parametrize("prec,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+def test_g6_residuals(golden, prec, rtol):
+    g = golden("g6_residuals.npz")
+    for i in range(int(g["n_cases"])):
+        p = "c%d_" % i
+        H, A, gg = g[p + "H"], g[p + "A"], g[p + "g"]
+        mm = A.shape[0]
+        m = _model(H, gg, A, np.full(mm, -np.inf), np.full(mm, np.inf), precision=prec)
+        m.warm_start(x=g[p + "x"], z=g[p + "z"], lam=g[p + "lam"])
+        pri, dua, rho, J = [float(v) for v in m.compute_residuals(float(g[p + "rho_in"]))]
+        floor = 1e-12 if prec == torch.float64 else 1e-5         # cancellation floor of O(1..10) sums
+        np.testing.assert_allclose(pri, g[p + "pri"], rtol=rtol, atol=floor)
+        np.testing.assert_allclose(dua, g[p + "dua"], rtol=rtol, atol=floor * 10)
+        np.testing.assert_allclose(J, g[p + "J"], rtol=max(rtol, 1e-6), atol=floor)
+        if np.isnan(g[p + "rho_out"]):
+            assert np.isnan(rho)                                   # Q17: 0/0 stays NaN through the clamp
+        elif prec == torch.float64 or i < 4:                       # clamp cases need fp64 cancellation
+            np.testing.assert_allclose(rho, g[p + "rho_out"], rtol=max(rtol * 10, 1e-5))
+
+
+# ---------------------------------------------------- G7: K with equality rows (Q15)
+@pytest.mark.parametrize("prec,rtol", [(torch.float64, 1e-8), (torch.float32, 1e-5)])
+def test_g7_K(golden, prec, rtol):
+    g = golden("g7_matrices.npz")
+    m = _model(*_qp(g), precision=prec)
+    for j in (3, 7, 12):
+        K = _np(m.layers.K(j))
+        Kg = g["K%d" % j]
+        np.testing.assert_allclose(K, Kg, rtol=rtol, atol=rtol * np.abs(Kg).max())
+
+
+# ------------------------------------------------------------ batch == per-instance
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,n_eq,n_ineq,B", [(10, 5, 15, 33), (32, 8, 56, 40), (7, 2, 4, 16)])
+def test_batch_matches_oracle(prec, n, n_eq, n_ineq, B):
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=100, feasible=True)
+    m = _model(H, g, A, l, u, precision=prec)
+    res = m.solve()
+    ref = O.solve_batch(H, g, A, l, u, form="factored")
+    it = res.info.iter.cpu().numpy()
+    if prec == torch.float64:
+        assert np.array_equal(it, ref["iter"])
+        np.testing.assert_allclose(_np(res.x), ref["x"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(_np(res.z), ref["z"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(_np(res.y), ref["lam"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(res.info.rho_ind.cpu().numpy(), ref["rho_ind"])
+        np.testing.assert_allclose(_np(res.info.obj_val), ref["obj_val"], rtol=1e-6, atol=1e-7)
+    else:
+        # float32: a marginal check may land one check apart on a few instances
+        assert np.mean(it == ref["iter"]) >= 0.9 and np.all(np.abs(it - ref["iter"]) <= 25)
+        same = it == ref["iter"]
+        np.testing.assert_allclose(_np(res.x)[same], ref["x"][same], rtol=0, atol=5e-5 * np.abs(ref["x"]).max())
+    assert res.info.status == ref["status"] or prec == torch.float32
+    assert all(s == "solved" for s in res.info.status)
+    # each instance solved alone gives bit-identical results to its slot in the batch
+    for b in (0, B - 1):
+        mb = _model(H[b], g[b], A[b], l[b], u[b], precision=prec)
+        rb = mb.solve()
+        assert rb.info.iter == int(it[b])
+        assert torch.equal(rb.x, res.x[b]) and torch.equal(rb.z, res.z[b])
+
+
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+def test_shared_matrices_batch(prec):
+    """Un-batched H, A shared by the batch (linear-MPC shape): same as replicating them."""
+    B, n, n_eq, n_ineq = 24, 12, 3, 20
+    H, g0, A, l0, u0, _ = utils.rand_qp(n, n_eq, n_ineq, seed=5, compute_sol=False, feasible=True)
+    g = np.stack([utils.update_qp(H, A, n_eq, n_ineq, seed=50 + b, compute_sol=False, feasible=True)[1] for b in range(B)])
+    lu = [utils.update_qp(H, A, n_eq, n_ineq, seed=50 + b, compute_sol=False, feasible=True)[3:5] for b in range(B)]
+    l = np.stack([x[0] for x in lu])
+    u = np.stack([x[1] for x in lu])
+    ms = _model(H, g, A, l, u, precision=prec)
+    rs = ms.solve()
+    mr = _model(np.broadcast_to(H, (B, n, n)).copy(), g, np.broadcast_to(A, (B,) + A.shape).copy(), l, u, precision=prec)
+    rr = mr.solve()
+    assert torch.equal(rs.info.iter, rr.info.iter)
+    assert torch.equal(rs.x, rr.x) and torch.equal(rs.z, rr.z)
+    assert all(s == "solved" for s in rs.info.status)
+
+
+# ----------------------------------------------------------- warm start / settings
+def test_warm_start_and_settings(golden):
+    g = golden("g3_c1_feasible.npz")
+    H, gg, A, l, u = _qp(g, "s0_")
+    m = _model(H, gg, A, l, u)
+    res = m.solve()
+    x, z, y = res.x.clone(), res.z.clone(), res.y.clone()
+    m2 = _model(H, gg, A, l, u)
+    m2.warm_start(x=x, z=_np(z), lam=y, rho=float(m.layers.rhos[m.rho_ind]))     # Q6 fixed: takes effect
+    st, ri = m2.get_state()
+    assert ri == m.rho_ind
+    np.testing.assert_array_equal(_np(st), np.concatenate([_np(x), _np(z), _np(y)]))
+    r2 = m2.solve()
+    assert r2.info.iter == 25 and r2.info.status == "solved"       # already converged: first check
+    m2.clear_primal_dual()
+    st, ri = m2.get_state()
+    assert np.all(_np(st) == 0) and ri == 7
+    m2.update_settings(eps_abs=1e-6, max_iter=50)
+    r3 = m2.solve()
+    assert r3.info.status == "max_iters_reached" and r3.info.iter == 50
+    m2.update_settings(eps_ab=1e-3, max_iter=4000)                 # Q8: the reference's typo is tolerated
+    assert m2.settings.eps_abs == 1e-3
+    with pytest.raises(ValueError):
+        m2.update_settings(rho=1.0)
+    with pytest.raises(ValueError):
+        m2.update_settings(nonsense=1)
+
+
+def test_edge_shapes():
+    """n=1/m=1, all-infinite bounds (unconstrained), odd sizes, max_iter=0."""
+    m = _model(np.array([[2.0]]), np.array([-4.0]), np.array([[1.0]]), np.array([-np.inf]), np.array([1.0]))
+    r = m.solve()
+    assert r.info.status == "solved"
+    np.testing.assert_allclose(_np(r.x), [1.0], atol=2e-3)         # min x^2 - 4x s.t. x <= 1
+    rs = np.random.RandomState(3)
+    M = rs.randn(5, 5)
+    H = M.T @ M + np.eye(5)
+    gg = rs.randn(5)
+    A = rs.randn(9, 5)
+    mu = _model(H, gg, A, np.full(9, -np.inf), np.full(9, np.inf))
+    ru = mu.solve()
+    assert ru.info.status == "solved"
+    np.testing.assert_allclose(_np(ru.x), np.linalg.solve(H, -gg), atol=5e-3)
+    m0 = _model(H, gg, A, np.full(9, -1.0), np.full(9, 1.0), max_iter=0)
+    r0 = m0.solve()
+    assert r0.info.status == "max_iters_reached" and r0.info.iter == 0 and np.all(_np(r0.x) == 0)
+
+
+# --------------------------------------------------- full-size properties (C2 config)
+def test_c2_full_size_properties():
+    """B=1024, n=100, m=300, float32 (BASELINE config 2): every instance solved; KKT residuals
+    recomputed independently in float64 on the device; planted optimum recovered."""
+    B, n, n_eq, n_ineq = 1024, 100, 25, 275
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=0, feasible=True)
+    m = _model(H, g, A, l, u, precision=torch.float32)
+    res = m.solve()
+    assert all(s == "solved" for s in res.info.status)
+    it = res.info.iter.cpu().numpy()
+    assert it.min() >= 50 and it.max() <= 600 and np.all(it % 25 == 0)
+    dev = res.x.device
+    Hd, Ad = torch.from_numpy(H).to(dev), torch.from_numpy(A).to(dev)
+    gd = torch.from_numpy(g).to(dev)
+    x, z, y = res.x.double(), res.z.double(), res.y.double()
+    Ax = torch.einsum("bmn,bn->bm", Ad, x)
+    pri = (Ax - z).abs().amax(1)
+    dua = (torch.einsum("bij,bj->bi", Hd, x) + torch.einsum("bmn,bm->bn", Ad, y) + gd).abs().amax(1)
+    assert float(pri.max()) < 1e-3 * np.sqrt(300) * 1.01 and float(dua.max()) < 1e-3 * np.sqrt(100) * 1.05
+    np.testing.assert_allclose(_np(res.info.pri_res), _np(pri), rtol=1e-2, atol=1e-5)
+    np.testing.assert_allclose(_np(res.info.dua_res), _np(dua), rtol=5e-2, atol=2e-4)
+    ld, ud = torch.from_numpy(l).to(dev), torch.from_numpy(u).to(dev)
+    assert bool(((z >= ld - 1e-6) & (z <= ud + 1e-6)).all())       # z is the clipped iterate
+    err = (x - torch.from_numpy(xs).to(dev)).abs().amax(1)
+    assert float(err.max()) < 2e-2                                 # eps_abs=1e-3 accuracy around the planted optimum
+    # instances 0..2 are the golden G4 problems: same iteration counts as the reference
+    gold = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g4_c2_feasible.npz"))
+    for s in range(3):
+        assert int(it[s]) == int(gold["s%d_iter" % s])
+        np.testing.assert_allclose(_np(res.x[s]), gold["s%d_x" % s], rtol=0, atol=2e-5 * np.abs(gold["s%d_x" % s]).max())
+    # idempotence: a warm re-solve of a solved batch stops at the first check
+    r2 = m.solve()
+    assert int(r2.info.iter.max()) == 25
