@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec of the MI355X ReLU-QP hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one batched cold-start solve() of the per-GPU batch (default: 4096 random
+dense QPs, n=100, m=300, float32, feasible rand_qp generator of SURVEY.md 8(d), eps_abs
+1e-3, all reference defaults), inputs and the K(rho) table already resident in HBM.
+Instances are independent: each rank owns its own shard (weak scaling: 4096 per GPU),
+there is NO data-path collective; torch.distributed is used only for the barrier around
+the timed region and for the max-over-ranks / sum reductions of the reported numbers.
+
+Rank 0 prints ONE JSON line.  `value` = all QPs solved by all ranks / max-over-ranks time.
+`roofline` prices the ADMM kernel against the HBM roof using the ALGORITHMIC bytes of
+SURVEY.md 8(d): 4*(n^2 + m*n) bytes per instance-iteration (K and A streamed once); the
+resident design may exceed 1.0 of that roof.  `cpu_baseline` times the oracle
+(reference-faithful W-form, float64) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "reluqp-py_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--n-eq", type=int, default=25)
+    ap.add_argument("--n-ineq", type=int, default=275)
+    ap.add_argument("--eps-abs", type=float, default=1e-3)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--seed0", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
+    """Oracle (reference-faithful W form, float64, one instance at a time, BLAS threads = all
+    host cores: how the reference runs on CPU) on the first instances of the batch until the
+    time budget is spent.  Returns solve-only QP/s (setup amortised, like `value`)."""
+    from oracle import reluqp_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    t_setup = t_solve = 0.0
+    iters = 0
+    done = 0
+    t0 = time.perf_counter()
+    while done < H.shape[0] and (time.perf_counter() - t0) < budget_s:
+        qp = O.OracleQP(form="W", quirks=False)
+        qp.setup(H[done], g[done], A[done], l[done], u[done], eps_abs=eps_abs)
+        r = qp.solve()
+        t_setup += qp.info.setup_time
+        t_solve += r.info.run_time
+        iters += r.info.iter
+        done += 1
+    return {
+        "value": done / t_solve,
+        "unit": "QP/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d instances of the same batch, oracle W-form fp64 (dense (n+2m)^2 matvec per iteration, "
+                  "numpy/BLAS on %d threads), solve-only; incl. per-QP setup: %.2f QP/s; %.0f ADMM it/s"
+                  % (done, cores, done / (t_solve + t_setup), iters / t_solve),
+        "setup_plus_solve_value": done / (t_solve + t_setup),
+        "admm_iters_per_sec": iters / t_solve,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import reluqp.reluqpth as reluqpth
+    from reluqp import utils
+
+    B, n, m = args.batch, args.n, args.n_eq + args.n_ineq
+    prec = torch.float32 if args.precision == "f32" else torch.float64
+    esz = 4 if args.precision == "f32" else 8
+    # shard: rank r owns instances [r*B, (r+1)*B) of the global seed sequence
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + rank * B,
+                                            feasible=True)
+    model = reluqpth.ReLU_QP()
+    t0 = time.perf_counter()
+    model.setup(H, g, A, l, u, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False)
+    torch.cuda.synchronize(dev)
+    setup_s = time.perf_counter() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        res = model.solve()
+    barrier()
+    t0 = time.perf_counter()
+    kern_s = 0.0
+    for _ in range(args.steps):
+        res = model.solve()           # cold start every step (warm_starting=False clears the state)
+        kern_s += model.last_kernel_time
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    iters = res.info.iter.to(torch.float64)
+    sum_iters = float(iters.sum())
+    solved = float((res.info.status_code == 0).sum())
+    stats = torch.tensor([elapsed, kern_s / max(1, args.steps), setup_s], device=dev, dtype=torch.float64)
+    sums = torch.tensor([sum_iters, solved, float(B)], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    elapsed, kern_avg_s, setup_max = [float(v) for v in stats.cpu()]
+    tot_iters, tot_solved, tot_qps = [float(v) for v in sums.cpu()]
+
+    if rank == 0:
+        step_s = elapsed / args.steps
+        value = tot_qps / step_s
+        # algorithmic work per launch (one rank's launch): SURVEY.md 8(d)
+        b_iter = esz * (n * n + m * n)
+        f_iter = 2 * n * n + 4 * m * n
+        alg_bytes = sum_iters * b_iter
+        achieved = alg_bytes / kern_avg_s / 1e9
+        out = {
+            "metric": "QP solves/sec (batch=%d random dense QPs n=%d m=%d per GPU)" % (B, n, m),
+            "value": value,
+            "unit": "QP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "batch=%d/GPU random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds "
+                                   "%d.., eps_abs=%g, cold start, reference defaults" %
+                                   (B, n, m, args.n_eq, args.seed0, args.eps_abs),
+                       "global_batch": int(tot_qps), "parallelism": "batch-split x%d, no collectives" % world,
+                       "kernel": model.kernel},
+            "admm_iters_per_sec": tot_iters / step_s,
+            "mean_iters": tot_iters / tot_qps,
+            "solved_frac": tot_solved / tot_qps,
+            "setup_s": setup_max,
+            "setup_plus_solve_qps": tot_qps / (setup_max + step_s),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_admm_%s" % model.kernel, "kernel_ms": kern_avg_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "fp32_valu_tflops": sum_iters * f_iter / kern_avg_s / 1e12,
+                         "fp32_valu_frac": sum_iters * f_iter / kern_avg_s / 1e12 / FP32_VALU_PEAK_TFLOPS},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(H, g, A, l, u, args.eps_abs, args.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,10 @@ def load():
         raise RqpUnavailable(
             "librqp_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C reluqp-py_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # torch ships its own libamdhip64 (SONAME libamdhip64.so.7).  It must be mapped BEFORE our
+    # library so that both bind to ONE HIP runtime (streams and pointers are shared with torch);
+    # loading ours first would pull a second runtime from /opt/rocm into the process.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

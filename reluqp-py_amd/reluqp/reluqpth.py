@@ -240,11 +240,15 @@ class ReLU_QP(object):
                              pri_res=dbls[0].data_ptr(), dua_res=dbls[1].data_ptr(),
                              rho_estimate=dbls[2].data_ptr(), obj_val=dbls[3].data_ptr(),
                              trace=trace.data_ptr() if trace is not None else None, trace_cap=cap, reserved=0)
+            k0, k1 = self._events()
+            k0.record()
             _cabi.check(self._h, lib.rqp_solve(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
                                                ctypes.byref(ci), self._stream()), "rqp_solve")
+            k1.record()
             end.record()
             end.synchronize()
             run_time = start.elapsed_time(end) / 1000.0
+            self.last_kernel_time = k0.elapsed_time(k1) / 1000.0   # the ADMM launch alone (HIP events)
         self.last_trace = trace      # [batch][checks][pri, dua, rho_estimate, rho_ind before the move]
         if st.verbose:
             self._print_trace(trace)
