@@ -2,6 +2,7 @@
 // Host orchestration only: argument validation, workspace ownership, kernel dispatch.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -66,12 +67,18 @@ int argmin_abs(const std::vector<double>& r, double v) {   // np.argmin(np.abs(r
 void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
-                     (void**)&h->fscratch};
+                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     h->is_setup = false;
+    h->resident = false;
+    h->kernel_name = "generic";
+}
+
+hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    return h->resident ? rqp_launch_solve_resident(h, a, s) : rqp_launch_solve_generic(h, a, s);
 }
 
 SolveArgs make_solve_args(const rqp_handle* h) {
@@ -193,6 +200,17 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, rqp_launch_pack(h, a, s));
     HIP_TRY(h, rqp_launch_gram(h, a, s));
     HIP_TRY(h, rqp_launch_factor(h, a, s));
+    const char* force = getenv("RQP_FORCE_GENERIC");
+    if (rqp_resident_fits(h) && !(force && force[0] == '1')) {
+        size_t ae, ke, he;
+        rqp_resident_pack_elems(h, &ae, &ke, &he);
+        HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
+        HIP_TRY(h, rqp_launch_pack_resident(h, s));
+        h->resident = true;
+        h->kernel_name = "resident";
+    }
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
 }
@@ -252,7 +270,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     a.out_x = x; a.out_z = z; a.out_lam = lam;
     if (info) a.info = *info;
     if (a.info.trace && a.info.trace_cap < 1) return fail_arg(h, "rqp_solve: trace without capacity");
-    HIP_TRY(h, rqp_launch_solve_generic(h, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -263,7 +281,7 @@ int rqp_iterate(rqp_handle* h, int32_t k, void* stream) {
     SolveArgs a = make_solve_args(h);
     a.mode = 1;
     a.max_iter = k;
-    HIP_TRY(h, rqp_launch_solve_generic(h, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -276,7 +294,7 @@ int rqp_compute_residuals(rqp_handle* h, double rho_in, double* pri, double* dua
     a.mode = 2;
     a.rho_in = rho_in;
     a.r_pri = pri; a.r_dua = dua; a.r_rho = rho_out; a.r_obj = obj;
-    HIP_TRY(h, rqp_launch_solve_generic(h, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
     return RQP_OK;
 }
 

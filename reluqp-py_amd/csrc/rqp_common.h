@@ -42,6 +42,9 @@ struct rqp_handle {
     double* rhos_d = nullptr;
     double* fscratch = nullptr;   // factor workspace when n*n doubles exceed LDS
     size_t fscratch_elems = 0;
+    // resident kernel images (rqp_resident.hip): lane-linear register / LDS layouts
+    float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
+    bool resident = false;
 
     const char* kernel_name = "generic";
     std::string err;
@@ -84,5 +87,11 @@ hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* 
                                 int rho_ind, hipStream_t s);
 hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
 hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
+
+// resident (register/LDS) variant, float32 only
+bool rqp_resident_fits(const rqp_handle* h);
+size_t rqp_resident_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
+hipError_t rqp_launch_pack_resident(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_solve_resident(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 static inline int rqp_round_up(int v, int q) { return (v + q - 1) / q * q; }

