@@ -15,6 +15,9 @@
 //
 // Same recurrence and same check logic as k_admm_generic (rqp_admm.hip); see that file and
 // oracle/reluqp_oracle.py:forward_refine for the statement and the reference line citations.
+#include <cstdio>
+#include <cstdlib>
+
 #include "rqp_common.h"
 
 template <int CTRL>
@@ -161,6 +164,18 @@ __global__ void __launch_bounds__(256, 2) k_admm_resident(SolveArgs a, const flo
     set_rho_rows(ri);
     __syncthreads();
 
+    // where this lane deposits its share of the A' reduce-scatter (see prod_At): ONE address VGPR
+    float* pw_ptr;
+    int pw_n;
+    {
+        const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1;
+        const int cbase = H2 * b4 + H1 * b5;
+        int nval = b4 ? (H1 - H2) : H2;                 // entries of s2[] that are not step-B duplicates
+        if (b5 && cbase + nval > CB) nval = CB - cbase; // ... nor step-A duplicates
+        pw_n = (b3 == 0) ? nval : 0;
+        pw_ptr = part + wave * N + CB * q + cbase;
+    }
+
     // ---- products -----------------------------------------------------------------------
     // y[RB*p + r] = sum_c A[..][CB*q + c] * v[CB*q + c], summed over q: every q-lane gets all RB sums
     auto prod_A = [&](const float* v, float (&acc)[RB]) {
@@ -205,16 +220,12 @@ __global__ void __launch_bounds__(256, 2) k_admm_resident(SolveArgs a, const flo
         for (int i = 0; i < H2; ++i) s2[i] = (i + H2 < H1) ? swapsum16(s1[i], s1[i + H2]) : swapsum16(s1[i], s1[i]);
 #pragma unroll
         for (int i = 0; i < H2; ++i) s2[i] += dppf<0x128>(s2[i]);       // row_ror:8 (xor 8)
-        const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1;
-        if (b3 == 0) {
+        // lane class (b5, b4) now holds the wave totals of columns cbase .. cbase + nval - 1:
+        //   s2[i] <-> column i + H2*b4 + H1*b5 ; the tail entries of the odd classes are duplicates
+        if (pw_n > 0) {
 #pragma unroll
-            for (int i = 0; i < H2; ++i) {
-                const bool dupB = b4 && (i + H2 >= H1);
-                const int iB = (b4 && !dupB) ? i + H2 : i;
-                const bool dupA = b5 && (iB + H1 >= CB);
-                const int iA = (b5 && !dupA) ? iB + H1 : iB;
-                if (!dupA && !dupB) part[wave * N + CB * q + iA] = s2[i];
-            }
+            for (int i = 0; i < H2; ++i)
+                if (i < pw_n) pw_ptr[i] = s2[i];
         }
     };
     // H x -> hx[KR*p + r]   (H from LDS, lane-linear b128 image)
@@ -516,6 +527,16 @@ hipError_t rqp_launch_solve_resident(const rqp_handle* h, const SolveArgs& a, hi
     const size_t lds = CfgC2::lds_bytes();
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_resident<CfgC2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (const char* dbg = getenv("RQP_DEBUG")) {
+        if (dbg[0] == '1') {
+            int nb = -1;
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_resident<CfgC2>, CfgC2::NT, lds);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, (const void*)k_admm_resident<CfgC2>);
+            fprintf(stderr, "[rqp] k_admm_resident: blocks/CU=%d (err %d) lds=%zu B static_lds=%zu regs=%d scratch=%zu B\n", nb, (int)oe,
+                    lds, (size_t)fa.sharedSizeBytes, fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
     k_admm_resident<CfgC2><<<h->B, CfgC2::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack);
     return hipGetLastError();
 }
