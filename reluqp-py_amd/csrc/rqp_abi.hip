@@ -74,11 +74,14 @@ void free_ws(rqp_handle* h) {
     }
     h->is_setup = false;
     h->resident = false;
+    h->res_kind = 0;
     h->kernel_name = "generic";
 }
 
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    return h->resident ? rqp_launch_solve_resident(h, a, s) : rqp_launch_solve_generic(h, a, s);
+    if (h->resident && h->res_kind == 2) return rqp_launch_solve_res2(h, a, s);
+    if (h->resident) return rqp_launch_solve_resident(h, a, s);
+    return rqp_launch_solve_generic(h, a, s);
 }
 
 SolveArgs make_solve_args(const rqp_handle* h) {
@@ -201,15 +204,21 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, rqp_launch_gram(h, a, s));
     HIP_TRY(h, rqp_launch_factor(h, a, s));
     const char* force = getenv("RQP_FORCE_GENERIC");
-    if (rqp_resident_fits(h) && !(force && force[0] == '1')) {
+    const char* kind = getenv("RQP_RESIDENT");            // "1": first resident layout (A/B runs); default: layout 2
+    const bool want_v1 = kind && kind[0] == '1';
+    if (!(force && force[0] == '1') && (want_v1 ? rqp_resident_fits(h) : rqp_res2_fits(h))) {
         size_t ae, ke, he;
-        rqp_resident_pack_elems(h, &ae, &ke, &he);
+        if (want_v1)
+            rqp_resident_pack_elems(h, &ae, &ke, &he);
+        else
+            rqp_res2_pack_elems(h, &ae, &ke, &he);
         HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
-        HIP_TRY(h, rqp_launch_pack_resident(h, s));
+        HIP_TRY(h, want_v1 ? rqp_launch_pack_resident(h, s) : rqp_launch_pack_res2(h, s));
         h->resident = true;
-        h->kernel_name = "resident";
+        h->res_kind = want_v1 ? 1 : 2;
+        h->kernel_name = want_v1 ? "resident" : "resident2";
     }
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)

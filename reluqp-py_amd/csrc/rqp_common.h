@@ -45,6 +45,7 @@ struct rqp_handle {
     // resident kernel images (rqp_resident.hip): lane-linear register / LDS layouts
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
     bool resident = false;
+    int res_kind = 0;             // 1: rqp_resident.hip (row-block layout), 2: rqp_resident2.hip (column block per wave)
 
     const char* kernel_name = "generic";
     std::string err;
@@ -93,5 +94,10 @@ bool rqp_resident_fits(const rqp_handle* h);
 size_t rqp_resident_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
 hipError_t rqp_launch_pack_resident(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_resident(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+
+bool rqp_res2_fits(const rqp_handle* h);
+void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 static inline int rqp_round_up(int v, int q) { return (v + q - 1) / q * q; }

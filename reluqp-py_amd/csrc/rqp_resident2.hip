@@ -1,0 +1,617 @@
+// rqp_resident2.hip -- RESIDENT ADMM kernel, second layout ("column block per wave").
+// Same recurrence, checks and semantics as k_admm_generic (rqp_admm.hip; reference
+// ReLU-QP-py/reluqp/reluqpth.py:201-249, statement in oracle/reluqp_oracle.py:forward_refine).
+//
+// One 256-thread workgroup = one QP; 2 workgroups per CU.  Wave w (of 4) owns the column block
+// [CW*w, CW*w + CW) of A (CW = 26) for ALL rows, and the matching CW rows of K and H:
+//
+//   A' nu  : thread (pl = lane>>1, q = lane&1) holds rows RB*pl.., cols CW*w + CQ*q..  (RB x CQ = 10 x 13,
+//            65 float2 VGPR pairs).  Reducing over pl stays INSIDE the wave (permlane32/16 swaps + DPP), so the
+//            wave produces its 26 entries of d = H x + g + A' nu with no cross-wave step.
+//   K d    : thread (rr = lane>>3, cc = lane&7) holds rows CW*w + KR*rr.., cols KC*cc..  (4 x 13); reduce over cc by
+//            DPP; the wave ends up owning dx and x for its own 26 columns.
+//   A dx   : needs only the wave's own 26 dx values (wave-local LDS hop, no barrier); the 4 per-wave partial row
+//            sums meet in LDS and are added, in fixed order, by the row's owner thread (row i <-> thread i % 256).
+//   H x    : as K d, H from a lane-linear LDS image.
+//
+// Barriers per iteration: 3 (nu visible / d visible / partials + x visible) instead of 4 + a d-assembly phase in
+// the first resident kernel; all FMAs are v_pk_fma_f32 on row pairs (the same register pairing serves A dx and A' nu).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rqp_common.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// hipcc (ROCm 7.2) miscompiles `r = __builtin_amdgcn_permlane32_swap(..); r.x + r.y` (both extracts read the
+// first result): inline asm, with the 2 wait states a VALU-written operand needs before a permlane swap.
+__device__ __forceinline__ float swsum32(float a, float b) {      // lower half: a.lo+a.hi ; upper half: b.lo+b.hi
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swsum16(float a, float b) {      // even rows: a.even+a.odd ; odd rows: b.even+b.odd
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <typename T>
+__device__ __forceinline__ T tmax2(T a, T b) {                    // NaN-propagating max (torch semantics)
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+
+template <int RB_, int CQ_, int KR_, int KC_>
+struct Res2Cfg {
+    static constexpr int RB = RB_, CQ = CQ_, KR = KR_, KC = KC_;
+    static constexpr int NT = 256, NW = 4, NQ = 2, PL = 32;
+    static constexpr int RP = RB / 2, KP = KR / 2;
+    static constexpr int CW = NQ * CQ;           // columns per wave
+    static constexpr int N = NW * CW;            // padded columns
+    static constexpr int M = PL * RB;            // padded rows
+    static constexpr int ND = ((N > 8 * KC ? N : 8 * KC) + 8 + 3) / 4 * 4;   // vector length incl. prefetch slack
+    static constexpr int AE2 = RP * CQ;          // A float2 pairs per thread
+    static constexpr int KE2 = KP * KC;          // K / H float2 pairs per thread
+    static constexpr int HU = KE2 / 2;           // H 16-byte units per thread
+    static constexpr int H1 = (CQ + 1) / 2, H2 = (H1 + 1) / 2;
+    static_assert(RB % 2 == 0 && KR % 2 == 0 && KE2 % 2 == 0, "row pairs");
+    static_assert(8 * KR >= CW && 8 * KC >= N && M <= 2 * NT, "tile shape");
+    static constexpr size_t lds_bytes() {
+        return (size_t)M * 8 * 4 + ND * 8 + 16 * 8       // zt64 lam64 z64 inv64 | x64 | redd
+               + (size_t)M * 4 * 4                       // lT uT rv32 nu
+               + (size_t)ND * 4 * 6                      // xin dxv hx hg gT dvec
+               + (size_t)NW * M * 4 + 64 * 4             // part, red
+               + (size_t)HU * NT * 16;                   // Hs
+    }
+};
+
+// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles wave 0 spends
+// in each segment of the iteration into `dbg` (never read by the kernel; never timed as the product).
+template <class C, bool DIAG>
+__global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* __restrict__ Apack,
+                                                      const float* __restrict__ Kpack,
+                                                      const float* __restrict__ Hpack, unsigned long long* dbg) {
+    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, NW = C::NW, RP = C::RP, KP = C::KP;
+    constexpr int CW = C::CW, N = C::N, M = C::M, ND = C::ND, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, H1 = C::H1, H2 = C::H2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* zt64 = (double*)smem_raw;                    // [M] A x        (row i owned by thread i % 256)
+    double* lam64 = zt64 + M;
+    double* z64 = lam64 + M;
+    double* inv64 = z64 + M;                              // 1 / rho_i
+    double* x64 = inv64 + M;                              // [ND]
+    double* redd = x64 + ND;                              // [16]
+    float* lT = (float*)(redd + 16);                      // [M]
+    float* uT = lT + M;
+    float* rv32 = uT + M;
+    float* nu = rv32 + M;                                 // [M] nu (lam at a check)
+    float* xin = nu + M;                                  // [ND] float(x)
+    float* dxv = xin + ND;                                // [ND] dx
+    float* hx = dxv + ND;                                 // [ND] H x
+    float* hg = hx + ND;                                  // [ND] H x + g
+    float* gT = hg + ND;                                  // [ND]
+    float* dvec = gT + ND;                                // [ND] d (A' lam at a check)
+    float* part = dvec + ND;                              // [NW][M] per-wave partial row sums of A dx
+    float* red = part + NW * M;                           // [64]
+    float* Hs = red + 64;                                 // [HU][NT][4]
+    static_assert(((size_t)M * 8 * 4 + ND * 8 + 16 * 8 + (size_t)M * 4 * 4 + ND * 4 * 6 + NW * M * 4 + 64 * 4) % 16 == 0,
+                  "H image must start 16-byte aligned");
+
+    const int n = a.n, m = a.m;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
+    const size_t mat = (a.sA == 0) ? 0 : (size_t)b;
+    const float* cg = (const float*)a.c + (size_t)b * m;
+
+    // ---- matrices: A, K_j -> VGPR pairs ; H -> LDS  (each element read from HBM once per solve)
+    f2 ar[RP][CQ];
+    {
+        const f2* Ap = (const f2*)(Apack + mat * (size_t)AE2 * NT * 2) + tid;
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp)
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) ar[rp][c] = Ap[(size_t)(rp * CQ + c) * NT];
+        const float4* Hp = (const float4*)(Hpack + mat * (size_t)HU * NT * 4);
+#pragma unroll
+        for (int u = 0; u < HU; ++u) ((float4*)Hs)[u * NT + tid] = Hp[u * NT + tid];
+    }
+    int ri = a.rho_ind[b];
+    f2 kr[KP][KC];
+    auto load_K = [&](int j) {
+        const f2* Kp = (const f2*)(Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT * 2) + tid;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) kr[kp][c] = Kp[(size_t)(kp * KC + c) * NT];
+    };
+    load_K(ri);
+
+    // ---- vectors.  Row i is initialised, updated and re-scaled by the SAME thread (i % 256): no barriers needed
+    auto set_rho_rows = [&](int j) {
+        const float rho = (float)a.rhos[j];
+        for (int i = tid; i < M; i += NT) {
+            const float rv = rho * ((i < m) ? cg[i] : 1.f);
+            rv32[i] = rv;
+            inv64[i] = 1.0 / (double)rv;
+        }
+    };
+    for (int i = tid; i < M; i += NT) {
+        const bool in = i < m;
+        zt64[i] = 0.0;
+        z64[i] = in ? a.z[(size_t)b * m + i] : 0.0;
+        lam64[i] = in ? a.lam[(size_t)b * m + i] : 0.0;
+        lT[i] = in ? ((const float*)a.l)[(size_t)b * m + i] : 0.f;
+        uT[i] = in ? ((const float*)a.u)[(size_t)b * m + i] : 0.f;
+        nu[i] = 0.f;
+    }
+    set_rho_rows(ri);
+    for (int i = tid; i < ND; i += NT) {
+        const bool in = i < n;
+        const double xv = in ? a.x[(size_t)b * n + i] : 0.0;
+        x64[i] = xv;
+        xin[i] = (float)xv;
+        gT[i] = in ? ((const float*)a.g)[(size_t)b * n + i] : 0.f;
+        hx[i] = 0.f;
+        hg[i] = 0.f;
+        dxv[i] = 0.f;
+        dvec[i] = 0.f;
+    }
+
+    // where this lane deposits its share of the A' reduce-scatter: columns colw .. colw + ncolw - 1
+    int colw, ncolw;
+    {
+        const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1;
+        const int cbase = H2 * b4 + H1 * b5;
+        int nval = b4 ? (H1 - H2) : H2;                   // entries that are not step-B duplicates
+        if (b5 && cbase + nval > CQ) nval = CQ - cbase;   // ... nor step-A duplicates
+        ncolw = ((lane & 0xE) == 0) ? nval : 0;           // one writer per (q, class): lane bits 1..3 == 0
+        colw = CW * wave + CQ * q + cbase;
+    }
+    __syncthreads();
+
+    // ---- products ------------------------------------------------------------------------------------
+    // wave partial of A v over the wave's CW columns -> part[wave][row]   (v: this wave's CW entries)
+    auto prod_A = [&](const float* v) {
+        float vc[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) vc[c] = v[CW * wave + CQ * q + c];
+        f2 acc[RP];
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
+            f2 s = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) s = __builtin_elementwise_fma(ar[rp][c], (f2){vc[c], vc[c]}, s);
+            s.x += dpp2<0xB1>(s.x);                                  // the other q (lane ^ 1)
+            s.y += dpp2<0xB1>(s.y);
+            acc[rp] = s;
+        }
+        if (q == 0) {
+            f2* dst = (f2*)(part + wave * M + RB * pl);
+#pragma unroll
+            for (int rp = 0; rp < RP; ++rp) dst[rp] = acc[rp];
+        }
+    };
+    // (A' w)[col] for the wave's own columns; out[col] = sum (+ addv[col] when ADD)
+    auto prod_At = [&](const float* w, float* out, const float* addv, bool add) {
+        float pre[H2];
+#pragma unroll
+        for (int i = 0; i < H2; ++i) pre[i] = add ? addv[colw + i] : 0.f;      // issued early: latency hides under the FMAs
+        f2 wr[RP];
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) wr[rp] = ((const f2*)(w + RB * pl))[rp];
+        float acc[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            f2 s = {0.f, 0.f};
+#pragma unroll
+            for (int rp = 0; rp < RP; ++rp) s = __builtin_elementwise_fma(ar[rp][c], wr[rp], s);
+            acc[c] = s.x + s.y;
+        }
+        // reduce-scatter over the 32 row groups of the wave (lane bits 5,4 by swaps; 3,2,1 by DPP)
+        float s1[H1];
+#pragma unroll
+        for (int i = 0; i < H1; ++i) s1[i] = (i + H1 < CQ) ? swsum32(acc[i], acc[i + H1]) : swsum32(acc[i], acc[i]);
+        float s2[H2];
+#pragma unroll
+        for (int i = 0; i < H2; ++i) s2[i] = (i + H2 < H1) ? swsum16(s1[i], s1[i + H2]) : swsum16(s1[i], s1[i]);
+#pragma unroll
+        for (int i = 0; i < H2; ++i) {
+            float v = s2[i];
+            v += dpp2<0x4E>(v);       // quad_perm [2,3,0,1]  (lane ^ 2)
+            v += dpp2<0x124>(v);      // row_ror:4
+            v += dpp2<0x128>(v);      // row_ror:8   -> sum over lane bits 2,3
+            s2[i] = v;
+        }
+        if (ncolw > 0) {
+#pragma unroll
+            for (int i = 0; i < H2; ++i)
+                if (i < ncolw) out[colw + i] = s2[i] + pre[i];
+        }
+    };
+    // y[CW*wave + KR*rr + r] = sum_c Mat[..][KC*cc + c] * v[KC*cc + c] summed over cc; lanes cc == 0 get the sums
+    auto prod_K = [&](const float* v, float (&s)[KR]) {
+        float vc[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) vc[c] = v[KC * cc + c];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            f2 t = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KC; ++c) t = __builtin_elementwise_fma(kr[kp][c], (f2){vc[c], vc[c]}, t);
+            s[2 * kp] = t.x;
+            s[2 * kp + 1] = t.y;
+        }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            float t = s[r];
+            t += dpp2<0xB1>(t);
+            t += dpp2<0x4E>(t);
+            t += dpp2<0x141>(t);      // row_half_mirror
+            s[r] = t;
+        }
+    };
+    auto prod_H = [&]() {
+        float vc[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) vc[c] = xin[KC * cc + c];
+        f2 acc[KP];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) acc[kp] = (f2){0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {                                 // one ds_read_b128 = two row pairs
+            const float4 t = ((const float4*)Hs)[u * NT + tid];
+            const int p0 = 2 * u, p1 = 2 * u + 1;
+            acc[p0 / KC] = __builtin_elementwise_fma((f2){t.x, t.y}, (f2){vc[p0 % KC], vc[p0 % KC]}, acc[p0 / KC]);
+            acc[p1 / KC] = __builtin_elementwise_fma((f2){t.z, t.w}, (f2){vc[p1 % KC], vc[p1 % KC]}, acc[p1 / KC]);
+        }
+        float s[KR];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            s[2 * kp] = acc[kp].x;
+            s[2 * kp + 1] = acc[kp].y;
+        }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            float t = s[r];
+            t += dpp2<0xB1>(t);
+            t += dpp2<0x4E>(t);
+            t += dpp2<0x141>(t);
+            if (cc == 0 && KR * rr + r < CW) {
+                const int j = CW * wave + KR * rr + r;
+                hx[j] = t;
+                hg[j] = t + gT[j];
+            }
+        }
+    };
+    // rows owned by this thread: tid (all waves) and tid + 256 (wave 0 only)
+    // do_a: A x += sum of the 4 wave partials ; z = clamp(A x + lam/rho)      (completes state k)
+    // do_b: lam_hat, nu of the NEXT iteration                                  (advances lam)
+    auto row_pass = [&](bool init, bool do_a, bool do_b) {
+        for (int i = tid; i < M; i += NT) {
+            double zt = zt64[i], z = z64[i];
+            if (init || do_a) {
+                const float adx = ((part[i] + part[M + i]) + part[2 * M + i]) + part[3 * M + i];
+                zt = (init ? 0.0 : zt) + (double)adx;
+                zt64[i] = zt;
+            }
+            if (do_a) {
+                const double v = zt + lam64[i] * inv64[i];
+                z = v;                                                 // torch.clamp: NaN stays NaN
+                if (v < (double)lT[i]) z = (double)lT[i];
+                if (v > (double)uT[i]) z = (double)uT[i];
+                z64[i] = z;
+            }
+            if (do_b) {
+                const double rv = (double)rv32[i];
+                const double pr = zt - z;
+                const double lh = lam64[i] + rv * pr;
+                lam64[i] = lh;
+                nu[i] = (float)(lh + rv * pr);
+            }
+        }
+    };
+
+    unsigned long long t_last = 0, t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int seg) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0) t_acc[seg] += t - t_last;
+            t_last = t;
+        }
+    };
+
+    float rho_est = (a.mode == 2) ? (float)a.rho_in : (float)a.rhos[ri];       // reluqpth.py:211
+    float pri = 0.f, dua = 0.f;
+    bool converged = false;
+    int iters = 0;
+    const float tolT = (float)a.tol;
+    const int kmax = (a.mode == 2) ? 0 : a.max_iter;
+
+    // ---- A x and H x of the incoming state
+    prod_A(xin);
+    __syncthreads();
+    prod_H();
+    row_pass(true, false, kmax > 0);
+
+    // ---- compute_residuals (reluqpth.py:307-318) on the current state (hx = H x valid)
+    auto residuals = [&](float rho_carry, float& o_pri, float& o_dua) -> float {
+        float v[7];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) v[e] = 0.f;
+        for (int i = tid; i < M; i += NT) {
+            nu[i] = (float)lam64[i];
+            v[0] = tmax2(v[0], fabsf((float)(zt64[i] - z64[i])));
+            v[1] = tmax2(v[1], fabsf((float)zt64[i]));
+            v[2] = tmax2(v[2], fabsf((float)z64[i]));
+        }
+        __syncthreads();
+        prod_At(nu, dvec, hg, false);                                  // t3 = A' lam
+        __syncthreads();
+        if (tid < N) {
+            const float t3 = dvec[tid];
+            v[3] = fabsf(hx[tid] + t3 + gT[tid]);
+            v[4] = fabsf(hx[tid]);
+            v[5] = fabsf(t3);
+            v[6] = fabsf(gT[tid]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int e = 0; e < 7; ++e) v[e] = tmax2(v[e], __shfl_xor(v[e], off, 64));
+        if (lane == 0)
+#pragma unroll
+            for (int e = 0; e < 7; ++e) red[wave * 8 + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            float r = red[e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) r = tmax2(r, red[w * 8 + e]);
+            v[e] = r;
+        }
+        __syncthreads();
+        o_pri = v[0];
+        o_dua = v[3];
+        const float num = v[0] / tmax2(v[1], v[2]);
+        const float den = v[3] / tmax2(tmax2(v[4], v[5]), v[6]);
+        float est = rho_carry * sqrtf(num / den);
+        if (est < (float)a.rho_min) est = (float)a.rho_min;             // torch.clamp: NaN stays NaN
+        if (est > (float)a.rho_max) est = (float)a.rho_max;
+        return est;
+    };
+
+    stamp(-1);
+    for (int k = 1; k <= kmax; ++k) {
+        __syncthreads();                                               // B3: nu (and hg) visible
+        stamp(0);
+        prod_At(nu, dvec, hg, true);                                   // d = H x + g + A' nu   (own columns)
+        stamp(1);
+        __syncthreads();                                               // B1: d visible
+        stamp(2);
+        {
+            float s[KR];
+            prod_K(dvec, s);                                           // K d
+            if (cc == 0) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+                    if (KR * rr + r < CW) {
+                        const int j = CW * wave + KR * rr + r;
+                        const float dx = -s[r];
+                        const double xn = x64[j] + (double)dx;
+                        x64[j] = xn;
+                        dxv[j] = dx;
+                        xin[j] = (float)xn;
+                    }
+            }
+        }
+        stamp(3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // dx of this wave's columns: same-wave LDS hop
+        __builtin_amdgcn_wave_barrier();
+        prod_A(dxv);                                                   // partial A dx
+        stamp(4);
+        __syncthreads();                                               // B2: partials and x visible
+        stamp(5);
+        prod_H();                                                      // H x of the new x (needed next iteration)
+        stamp(6);
+        iters = k;
+        const bool check = (a.mode == 0) && ((k % a.check_interval) == 0);    // reluqpth.py:218 (Q3 fixed)
+        if (!check) {
+            row_pass(false, true, k < kmax);
+            stamp(7);
+        } else {
+            row_pass(false, true, false);
+            const int ri_before = ri;
+            rho_est = residuals(rho_est, pri, dua);                    // :220 (Q4: carried estimate)
+            if (rho_est > (float)a.rhos[ri] * tolT && ri < a.nrho - 1)          // :223
+                ri += 1;
+            else if (rho_est < (float)a.rhos[ri] / tolT && ri > 0)              // :226
+                ri -= 1;
+            if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && tid == 0) {
+                double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
+                tr[0] = (double)pri; tr[1] = (double)dua; tr[2] = (double)rho_est; tr[3] = (double)ri_before;
+            }
+            if (pri < (float)a.thr_p && dua < (float)a.thr_d) {        // :233
+                converged = true;
+                break;
+            }
+            if (ri != ri_before) {                                     // adaptive-rho "re-factor": table lookup
+                load_K(ri);
+                set_rho_rows(ri);
+            }
+            if (k < kmax) row_pass(false, false, true);
+            stamp(8);
+        }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0)
+            for (int e = 0; e < 10; ++e) dbg[((size_t)b * 4 + wave) * 10 + e] = (e == 9) ? (unsigned long long)iters : t_acc[e];
+    }
+
+    __syncthreads();
+    if (a.mode == 1) {                                                 // iterate-only: keep the state
+        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[i];
+        for (int i = tid; i < m; i += NT) {
+            a.z[(size_t)b * m + i] = z64[i];
+            a.lam[(size_t)b * m + i] = lam64[i];
+        }
+        return;
+    }
+    if (!converged) rho_est = residuals(rho_est, pri, dua);            // :243 (Q11 fixed: fresh state)
+
+    // objective 1/2 x'Hx + g'x (compute_J :320-322)
+    double jp = 0.0;
+    if (tid < N) jp = (double)(xin[tid] * (0.5f * hx[tid] + gT[tid]));
+    for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
+    if (lane == 0) redd[wave] = jp;
+    __syncthreads();
+    const double obj = redd[0] + redd[1] + redd[2] + redd[3];
+
+    if (a.mode == 2) {
+        if (tid == 0) {
+            if (a.r_pri) a.r_pri[b] = (double)pri;
+            if (a.r_dua) a.r_dua[b] = (double)dua;
+            if (a.r_rho) a.r_rho[b] = (double)rho_est;
+            if (a.r_obj) a.r_obj[b] = obj;
+        }
+        return;
+    }
+
+    // ---- update_results (reluqpth.py:278-305)
+    if (a.out_x) for (int i = tid; i < n; i += NT) ((float*)a.out_x)[(size_t)b * n + i] = (float)x64[i];
+    if (a.out_z) for (int i = tid; i < m; i += NT) ((float*)a.out_z)[(size_t)b * m + i] = (float)z64[i];
+    if (a.out_lam) for (int i = tid; i < m; i += NT) ((float*)a.out_lam)[(size_t)b * m + i] = (float)lam64[i];
+    if (tid == 0) {
+        if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+        if (a.info.rho_ind) a.info.rho_ind[b] = ri;
+        if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
+        if (a.info.dua_res) a.info.dua_res[b] = (double)dua;
+        if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
+        if (a.info.obj_val) a.info.obj_val[b] = obj;
+    }
+    if (a.warm_starting) {                                             // state + rho index persist (:304)
+        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[i];
+        for (int i = tid; i < m; i += NT) {
+            a.z[(size_t)b * m + i] = z64[i];
+            a.lam[(size_t)b * m + i] = lam64[i];
+        }
+        if (tid == 0) a.rho_ind[b] = ri;
+    } else {                                                           // clear_primal_dual (:324-333)
+        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = 0.0;
+        for (int i = tid; i < m; i += NT) {
+            a.z[(size_t)b * m + i] = 0.0;
+            a.lam[(size_t)b * m + i] = 0.0;
+        }
+        if (tid == 0) a.rho_ind[b] = a.rho_ind0;
+    }
+}
+
+// ---------------------------------------------------------------------------- packing
+// Lane-linear images written once at setup:
+//   Apack[mat][pair = rp*CQ + c][t][2]      = A[RB*pl + 2rp + h][CW*w + CQ*q + c]
+//   Kpack[mat][j][pair = kp*KC + c][t][2]   = K_j[CW*w + KR*rr + 2kp + h][KC*cc + c]   (0 when KR*rr + 2kp + h >= CW)
+//   Hpack[mat][u][t][4]                     = pairs 2u, 2u+1 of H in the K layout
+template <class C>
+__global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
+                            const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
+                            float* __restrict__ Hpack) {
+    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU;
+    const int mat = blockIdx.y;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
+    const float* Am = A + (size_t)mat * m * ldn;
+    const float* Hm = Ht + (size_t)mat * n * ldn;
+    if (blockIdx.x == 0) {
+        float* Ap = Apack + (size_t)mat * AE2 * NT * 2;
+        for (int e = 0; e < AE2 * 2; ++e) {
+            const int pair = e >> 1, h = e & 1;
+            const int r = RB * pl + 2 * (pair / CQ) + h, c = CW * w + CQ * q + pair % CQ;
+            Ap[((size_t)pair * NT + t) * 2 + h] = (r < m && c < n) ? Am[(size_t)r * ldn + c] : 0.f;
+        }
+        float* Hp = Hpack + (size_t)mat * HU * NT * 4;
+        for (int e = 0; e < KE2 * 2; ++e) {
+            const int pair = e >> 1, h = e & 1;
+            const int lr = KR * rr + 2 * (pair / KC) + h;
+            const int r = CW * w + lr, c = KC * cc + pair % KC;
+            // H[r][c] = Ht[c][r]
+            Hp[((size_t)(pair >> 1) * NT + t) * 4 + (pair & 1) * 2 + h] = (lr < CW && r < n && c < n) ? Hm[(size_t)c * ldn + r] : 0.f;
+        }
+    } else {
+        const int j = blockIdx.x - 1;
+        const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
+        float* Kp = Kpack + ((size_t)mat * nrho + j) * KE2 * NT * 2;
+        for (int e = 0; e < KE2 * 2; ++e) {
+            const int pair = e >> 1, h = e & 1;
+            const int lr = KR * rr + 2 * (pair / KC) + h;
+            const int r = CW * w + lr, c = KC * cc + pair % KC;
+            Kp[((size_t)pair * NT + t) * 2 + h] = (lr < CW && r < n && c < n) ? Kj[(size_t)r * ldn + c] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+typedef Res2Cfg<10, 13, 4, 13> Cfg2C2;     // n <= 104, m <= 320
+
+bool rqp_res2_fits(const rqp_handle* h) { return h->esz == 4 && h->n <= Cfg2C2::N && h->m <= Cfg2C2::M; }
+
+void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
+    *a_elems = (size_t)h->nmat * Cfg2C2::AE2 * Cfg2C2::NT * 2;
+    *k_elems = (size_t)h->nmat * h->nrho * Cfg2C2::KE2 * Cfg2C2::NT * 2;
+    *h_elems = (size_t)h->nmat * Cfg2C2::HU * Cfg2C2::NT * 4;
+}
+
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
+    dim3 grid(1 + h->nrho, h->nmat);
+    k_pack_res2<Cfg2C2><<<grid, Cfg2C2::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+                                                      (const float*)h->K, h->Apack, h->Kpack, h->Hpack);
+    return hipGetLastError();
+}
+
+hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = Cfg2C2::lds_bytes();
+    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<Cfg2C2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (const char* dbg = getenv("RQP_DEBUG")) {
+        if (dbg[0] == '1') {
+            int nb = -1;
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<Cfg2C2, false>, Cfg2C2::NT, lds);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<Cfg2C2, false>);
+            fprintf(stderr, "[rqp] k_admm_res2: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", nb, (int)oe, lds,
+                    fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
+    if (const char* dg = getenv("RQP_DIAG")) {
+        if (dg[0] == '1') {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+            unsigned long long* dbg = nullptr;
+            const size_t cnt = (size_t)h->B * 4 * 10;
+            if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipFuncSetAttribute((const void*)k_admm_res2<Cfg2C2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k_admm_res2<Cfg2C2, true><<<h->B, Cfg2C2::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> hbuf(cnt);
+            (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(dbg);
+            static const char* names[9] = {"B3 wait", "A'nu", "B1 wait", "Kd+x", "A dx", "B2 wait", "H x", "rows", "check"};
+            for (int w = 0; w < 4; ++w) {
+                double tot[9] = {0}, its = 0;
+                for (int b = 0; b < h->B; ++b) {
+                    for (int e = 0; e < 9; ++e) tot[e] += (double)hbuf[((size_t)b * 4 + w) * 10 + e];
+                    its += (double)hbuf[((size_t)b * 4 + w) * 10 + 9];
+                }
+                fprintf(stderr, "[rqp diag] wave %d cycles/iteration:", w);
+                double sum = 0;
+                for (int e = 0; e < 9; ++e) { fprintf(stderr, " %s=%.0f", names[e], tot[e] / its); sum += tot[e] / its; }
+                fprintf(stderr, " | total=%.0f\n", sum);
+            }
+            return hipGetLastError();
+        }
+    }
+    k_admm_res2<Cfg2C2, false><<<h->B, Cfg2C2::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr);
+    return hipGetLastError();
+}
