@@ -88,15 +88,8 @@ def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from reluqp import distributed as D
+    rank, world, local_rank, dist = D.init()          # nccl (= RCCL) when WORLD_SIZE > 1; barrier/reductions only
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -107,9 +100,10 @@ def main():
     B, n, m = args.batch, args.n, args.n_eq + args.n_ineq
     prec = torch.float32 if args.precision == "f32" else torch.float64
     esz = 4 if args.precision == "f32" else 8
-    # shard: rank r owns instances [r*B, (r+1)*B) of the global seed sequence
-    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + rank * B,
-                                            feasible=True)
+    # weak scaling: the job is world*B instances; rank r owns the contiguous shard [r*B, (r+1)*B)
+    start, size = D.shard_range(world * B, rank, world)
+    assert size == B
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + start, feasible=True)
     model = reluqpth.ReLU_QP()
     t0 = time.perf_counter()
     model.setup(H, g, A, l, u, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False)
@@ -135,13 +129,8 @@ def main():
     iters = res.info.iter.to(torch.float64)
     sum_iters = float(iters.sum())
     solved = float((res.info.status_code == 0).sum())
-    stats = torch.tensor([elapsed, kern_s / max(1, args.steps), setup_s], device=dev, dtype=torch.float64)
-    sums = torch.tensor([sum_iters, solved, float(B)], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    elapsed, kern_avg_s, setup_max = [float(v) for v in stats.cpu()]
-    tot_iters, tot_solved, tot_qps = [float(v) for v in sums.cpu()]
+    elapsed, (kern_avg_s, setup_max), tot_iters, tot_solved, tot_qps = D.reduce_report(
+        dist, dev, elapsed, sum_iters, solved, B, extra_max=[kern_s / max(1, args.steps), setup_s])
 
     if rank == 0:
         step_s = elapsed / args.steps
