@@ -12,12 +12,14 @@
 //            DPP; the wave ends up owning dx and x for its own 26 columns.
 //   A dx   : needs only the wave's own 26 dx values (wave-local LDS hop, no barrier); the 4 per-wave partial row
 //            sums meet in LDS and are added, in fixed order, by the row's owner thread (row i <-> thread i % 256).
-//   H x    : as K d, H from a lane-linear LDS image.
+//   H x    : H is symmetric, so d = H x + g + A' nu = [A; H]' [nu; x] + g: the H rows (4 per lane, from a lane-linear
+//            LDS image) are simply appended to the A rows of the transposed product -- no separate H phase.
 //
 // Barriers per iteration: 3 (nu visible / d visible / partials + x visible) instead of 4 + a d-assembly phase in
 // the first resident kernel; all FMAs are v_pk_fma_f32 on row pairs (the same register pairing serves A dx and A' nu).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "rqp_common.h"
@@ -38,6 +40,30 @@ __device__ __forceinline__ float swsum16(float a, float b) {      // even rows: 
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
+__device__ __forceinline__ float wave_max(float v) {              // max over the 64 lanes, every lane gets it (NaN-free inputs)
+    v = fmaxf(v, dpp2<0xB1>(v));
+    v = fmaxf(v, dpp2<0x4E>(v));
+    v = fmaxf(v, dpp2<0x141>(v));
+    v = fmaxf(v, dpp2<0x128>(v));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = fmaxf(a, b);
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+    unsigned a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = a | b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a | b;
+}
 template <typename T>
 __device__ __forceinline__ T tmax2(T a, T b) {                    // NaN-propagating max (torch semantics)
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
@@ -51,17 +77,20 @@ struct Res2Cfg {
     static constexpr int CW = NQ * CQ;           // columns per wave
     static constexpr int N = NW * CW;            // padded columns
     static constexpr int M = PL * RB;            // padded rows
-    static constexpr int ND = ((N > 8 * KC ? N : 8 * KC) + 8 + 3) / 4 * 4;   // vector length incl. prefetch slack
+    static constexpr int SW = 8 * KR;            // vector slots per wave (>= CW): column j lives at SW*(j/CW) + j%CW
+    static constexpr int ND = NW * SW;           // padded vector length
     static constexpr int AE2 = RP * CQ;          // A float2 pairs per thread
     static constexpr int KE2 = KP * KC;          // K / H float2 pairs per thread
-    static constexpr int HU = KE2 / 2;           // H 16-byte units per thread
+    static constexpr int HR = 4, HP = HR / 2;    // H rows per row group in the transposed product (PL*HR >= N)
+    static constexpr int HE2 = HP * CQ;          // H float2 pairs per thread
+    static constexpr int HU = HE2 / 2;           // H 16-byte units per thread
     static constexpr int H1 = (CQ + 1) / 2, H2 = (H1 + 1) / 2;
-    static_assert(RB % 2 == 0 && KR % 2 == 0 && KE2 % 2 == 0, "row pairs");
-    static_assert(8 * KR >= CW && 8 * KC >= N && M <= 2 * NT, "tile shape");
+    static_assert(RB % 2 == 0 && KR % 2 == 0 && HP == 2 && HU == CQ && PL * HR >= N, "row pairs");
+    static_assert(8 * KR >= CW && 8 * KC >= N && M <= 2 * NT && KC == CQ && NQ == 2, "tile shape");
     static constexpr size_t lds_bytes() {
         return (size_t)M * 8 * 4 + ND * 8 + 16 * 8       // zt64 lam64 z64 inv64 | x64 | redd
                + (size_t)M * 4 * 4                       // lT uT rv32 nu
-               + (size_t)ND * 4 * 6                      // xin dxv hx hg gT dvec
+               + (size_t)ND * 4 * 6                      // xin xnat dxv hx gT dvec
                + (size_t)NW * M * 4 + 64 * 4             // part, red
                + (size_t)HU * NT * 16;                   // Hs
     }
@@ -74,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
                                                       const float* __restrict__ Kpack,
                                                       const float* __restrict__ Hpack, unsigned long long* dbg) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, NW = C::NW, RP = C::RP, KP = C::KP;
-    constexpr int CW = C::CW, N = C::N, M = C::M, ND = C::ND, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, H1 = C::H1, H2 = C::H2;
+    constexpr int CW = C::CW, N = C::N, M = C::M, ND = C::ND, SW = C::SW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HP = C::HP, HR = C::HR, H1 = C::H1, H2 = C::H2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* zt64 = (double*)smem_raw;                    // [M] A x        (row i owned by thread i % 256)
     double* lam64 = zt64 + M;
@@ -86,11 +115,11 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
     float* uT = lT + M;
     float* rv32 = uT + M;
     float* nu = rv32 + M;                                 // [M] nu (lam at a check)
-    float* xin = nu + M;                                  // [ND] float(x)
-    float* dxv = xin + ND;                                // [ND] dx
+    float* xin = nu + M;                                  // [ND] float(x), slot order (SW per wave)
+    float* xnat = xin + ND;                               // [ND] float(x), natural order (rows of H)
+    float* dxv = xnat + ND;                               // [ND] dx
     float* hx = dxv + ND;                                 // [ND] H x
-    float* hg = hx + ND;                                  // [ND] H x + g
-    float* gT = hg + ND;                                  // [ND]
+    float* gT = hx + ND;                                  // [ND]
     float* dvec = gT + ND;                                // [ND] d (A' lam at a check)
     float* part = dvec + ND;                              // [NW][M] per-wave partial row sums of A dx
     float* red = part + NW * M;                           // [64]
@@ -147,14 +176,15 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         nu[i] = 0.f;
     }
     set_rho_rows(ri);
-    for (int i = tid; i < ND; i += NT) {
-        const bool in = i < n;
-        const double xv = in ? a.x[(size_t)b * n + i] : 0.0;
+    for (int i = tid; i < ND; i += NT) {                  // slot i <-> column SW-block (i / SW), offset (i % SW)
+        const int col = CW * (i / SW) + (i % SW);
+        const bool in = (i % SW) < CW && col < n;
+        const double xv = in ? a.x[(size_t)b * n + col] : 0.0;
         x64[i] = xv;
         xin[i] = (float)xv;
-        gT[i] = in ? ((const float*)a.g)[(size_t)b * n + i] : 0.f;
+        xnat[i] = (i < n) ? (float)a.x[(size_t)b * n + i] : 0.f;
+        gT[i] = in ? ((const float*)a.g)[(size_t)b * n + col] : 0.f;
         hx[i] = 0.f;
-        hg[i] = 0.f;
         dxv[i] = 0.f;
         dvec[i] = 0.f;
     }
@@ -167,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         int nval = b4 ? (H1 - H2) : H2;                   // entries that are not step-B duplicates
         if (b5 && cbase + nval > CQ) nval = CQ - cbase;   // ... nor step-A duplicates
         ncolw = ((lane & 0xE) == 0) ? nval : 0;           // one writer per (q, class): lane bits 1..3 == 0
-        colw = CW * wave + CQ * q + cbase;
+        colw = SW * wave + CQ * q + cbase;
     }
     __syncthreads();
 
@@ -176,7 +206,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
     auto prod_A = [&](const float* v) {
         float vc[CQ];
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) vc[c] = v[CW * wave + CQ * q + c];
+        for (int c = 0; c < CQ; ++c) vc[c] = v[SW * wave + CQ * q + c];
         f2 acc[RP];
 #pragma unroll
         for (int rp = 0; rp < RP; ++rp) {
@@ -193,26 +223,60 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
             for (int rp = 0; rp < RP; ++rp) dst[rp] = acc[rp];
         }
     };
-    // (A' w)[col] for the wave's own columns; out[col] = sum (+ addv[col] when ADD)
-    auto prod_At = [&](const float* w, float* out, const float* addv, bool add) {
-        float pre[H2];
-#pragma unroll
-        for (int i = 0; i < H2; ++i) pre[i] = add ? addv[colw + i] : 0.f;      // issued early: latency hides under the FMAs
+    // Transposed product for the wave's own columns, reduced over the wave's 32 row groups:
+    //   USE_A: + sum_rows A[row][col] * w[row]          (w = nu, or lam at a check)
+    //   USE_H: + sum_rows H[row][col] * xnat[row]       (= (H x)[col], H symmetric)
+    //   out[slot(col)] = sum (+ gT when addg)
+    auto prod_At = [&](auto use_a, auto use_h, const float* w, float* out, bool addg) {
+        constexpr bool USE_A = decltype(use_a)::value, USE_H = decltype(use_h)::value;
         f2 wr[RP];
+        f2 wx[HP];
+        if constexpr (USE_A) {
 #pragma unroll
-        for (int rp = 0; rp < RP; ++rp) wr[rp] = ((const f2*)(w + RB * pl))[rp];
-        float acc[CQ];
-#pragma unroll
-        for (int c = 0; c < CQ; ++c) {
-            f2 s = {0.f, 0.f};
-#pragma unroll
-            for (int rp = 0; rp < RP; ++rp) s = __builtin_elementwise_fma(ar[rp][c], wr[rp], s);
-            acc[c] = s.x + s.y;
+            for (int rp = 0; rp < RP; ++rp) wr[rp] = ((const f2*)(w + RB * pl))[rp];
         }
-        // reduce-scatter over the 32 row groups of the wave (lane bits 5,4 by swaps; 3,2,1 by DPP)
-        float s1[H1];
+        if constexpr (USE_H) {
+            const float4 xv = *(const float4*)(xnat + HR * pl);        // x of this lane group's 4 rows of H
+            wx[0] = (f2){xv.x, xv.y};
+            wx[1] = (f2){xv.z, xv.w};
+        }
+        // column sum over this lane's rows: A rows from VGPRs first, then the 4 H rows of one ds_read_b128 that was
+        // issued one column earlier (software pipeline of depth 1: its latency hides under the A-row FMAs)
+        auto hload = [&](int c) -> float4 { return ((const float4*)Hs)[c * NT + tid]; };
+        auto colsum = [&](int c, const float4& hv) -> float {
+            f2 t2 = {0.f, 0.f};
+            if constexpr (USE_A) {
 #pragma unroll
-        for (int i = 0; i < H1; ++i) s1[i] = (i + H1 < CQ) ? swsum32(acc[i], acc[i + H1]) : swsum32(acc[i], acc[i]);
+                for (int rp = 0; rp < RP; ++rp) t2 = __builtin_elementwise_fma(ar[rp][c], wr[rp], t2);
+            }
+            if constexpr (USE_H) {
+                t2 = __builtin_elementwise_fma((f2){hv.x, hv.y}, wx[0], t2);
+                t2 = __builtin_elementwise_fma((f2){hv.z, hv.w}, wx[1], t2);
+            }
+            return t2.x + t2.y;
+        };
+        // reduce-scatter over the 32 row groups of the wave (lane bits 5,4 by swaps; 3,2,1 by DPP); columns are
+        // produced in the order the first swap level consumes them (0, H1, 1, H1+1, ...), so few sums are live
+        float s1[H1];
+        float4 hcur = {0.f, 0.f, 0.f, 0.f}, hnext = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (USE_H) hcur = hload(0);
+#pragma unroll
+        for (int i = 0; i < H1; ++i) {
+            const bool pair = (i + H1 < CQ);
+            if constexpr (USE_H) hnext = pair ? hload(i + H1) : ((i + 1 < H1) ? hload(i + 1) : hcur);
+            const float a0 = colsum(i, hcur);
+            if (pair) {
+                if constexpr (USE_H) hcur = (i + 1 < H1) ? hload(i + 1) : hnext;
+                const float a1 = colsum(i + H1, hnext);
+                s1[i] = swsum32(a0, a1);
+            } else {
+                if constexpr (USE_H) hcur = hnext;
+                s1[i] = swsum32(a0, a0);
+            }
+        }
+        float gpre[H2];
+#pragma unroll
+        for (int i = 0; i < H2; ++i) gpre[i] = addg ? gT[colw + i] : 0.f;     // lands while the reduction runs
         float s2[H2];
 #pragma unroll
         for (int i = 0; i < H2; ++i) s2[i] = (i + H2 < H1) ? swsum16(s1[i], s1[i + H2]) : swsum16(s1[i], s1[i]);
@@ -227,14 +291,16 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         if (ncolw > 0) {
 #pragma unroll
             for (int i = 0; i < H2; ++i)
-                if (i < ncolw) out[colw + i] = s2[i] + pre[i];
+                if (i < ncolw) out[colw + i] = s2[i] + gpre[i];
         }
     };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
     // y[CW*wave + KR*rr + r] = sum_c Mat[..][KC*cc + c] * v[KC*cc + c] summed over cc; lanes cc == 0 get the sums
     auto prod_K = [&](const float* v, float (&s)[KR]) {
         float vc[KC];
 #pragma unroll
-        for (int c = 0; c < KC; ++c) vc[c] = v[KC * cc + c];
+        for (int c = 0; c < KC; ++c) vc[c] = v[SW * (cc >> 1) + CQ * (cc & 1) + c];
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             f2 t = {0.f, 0.f};
@@ -250,39 +316,6 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
             t += dpp2<0x4E>(t);
             t += dpp2<0x141>(t);      // row_half_mirror
             s[r] = t;
-        }
-    };
-    auto prod_H = [&]() {
-        float vc[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) vc[c] = xin[KC * cc + c];
-        f2 acc[KP];
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) acc[kp] = (f2){0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {                                 // one ds_read_b128 = two row pairs
-            const float4 t = ((const float4*)Hs)[u * NT + tid];
-            const int p0 = 2 * u, p1 = 2 * u + 1;
-            acc[p0 / KC] = __builtin_elementwise_fma((f2){t.x, t.y}, (f2){vc[p0 % KC], vc[p0 % KC]}, acc[p0 / KC]);
-            acc[p1 / KC] = __builtin_elementwise_fma((f2){t.z, t.w}, (f2){vc[p1 % KC], vc[p1 % KC]}, acc[p1 / KC]);
-        }
-        float s[KR];
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
-            s[2 * kp] = acc[kp].x;
-            s[2 * kp + 1] = acc[kp].y;
-        }
-#pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            float t = s[r];
-            t += dpp2<0xB1>(t);
-            t += dpp2<0x4E>(t);
-            t += dpp2<0x141>(t);
-            if (cc == 0 && KR * rr + r < CW) {
-                const int j = CW * wave + KR * rr + r;
-                hx[j] = t;
-                hg[j] = t + gT[j];
-            }
         }
     };
     // rows owned by this thread: tid (all waves) and tid + 256 (wave 0 only)
@@ -335,7 +368,6 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
     // ---- A x and H x of the incoming state
     prod_A(xin);
     __syncthreads();
-    prod_H();
     row_pass(true, false, kmax > 0);
 
     // ---- compute_residuals (reluqpth.py:307-318) on the current state (hx = H x valid)
@@ -350,29 +382,43 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
             v[2] = tmax2(v[2], fabsf((float)z64[i]));
         }
         __syncthreads();
-        prod_At(nu, dvec, hg, false);                                  // t3 = A' lam
+        if (tid < ND && (tid % SW) >= CW) {                              // padding slots: exact zeros
+            dxv[tid] = 0.f;
+            hx[tid] = 0.f;
+        }
+        prod_At(YES, NO, nu, dxv, false);                              // t3 = A' lam  (dxv is dead here: scratch)
+        prod_At(NO, YES, nu, hx, false);                               // t2 = H x
         __syncthreads();
-        if (tid < N) {
-            const float t3 = dvec[tid];
+        if (tid < ND) {                                                 // padding slots hold zeros
+            const float t3 = dxv[tid];
             v[3] = fabsf(hx[tid] + t3 + gT[tid]);
             v[4] = fabsf(hx[tid]);
             v[5] = fabsf(t3);
             v[6] = fabsf(gT[tid]);
         }
+        // wave max of 7 values + NaN mask (torch max/norm propagate NaN): v_max (IEEE maxNum) on DPP / permlane swaps
+        unsigned nanm = 0;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
+        for (int e = 0; e < 7; ++e) nanm |= (v[e] != v[e]) ? (1u << e) : 0u;
+        float nm = __builtin_bit_cast(float, nanm);                    // bit pattern; OR-reduced with integer ops below
 #pragma unroll
-            for (int e = 0; e < 7; ++e) v[e] = tmax2(v[e], __shfl_xor(v[e], off, 64));
-        if (lane == 0)
+        for (int e = 0; e < 7; ++e) v[e] = wave_max(v[e]);
+        nanm = wave_or(__builtin_bit_cast(unsigned, nm));
+        if (lane == 0) {
 #pragma unroll
             for (int e = 0; e < 7; ++e) red[wave * 8 + e] = v[e];
+            red[wave * 8 + 7] = __builtin_bit_cast(float, nanm);
+        }
         __syncthreads();
+        nanm = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) nanm |= __builtin_bit_cast(unsigned, red[w * 8 + 7]);
 #pragma unroll
         for (int e = 0; e < 7; ++e) {
             float r = red[e];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) r = tmax2(r, red[w * 8 + e]);
-            v[e] = r;
+            for (int w = 1; w < NW; ++w) r = fmaxf(r, red[w * 8 + e]);
+            v[e] = ((nanm >> e) & 1u) ? __builtin_nanf("") : r;
         }
         __syncthreads();
         o_pri = v[0];
@@ -389,24 +435,24 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
     for (int k = 1; k <= kmax; ++k) {
         __syncthreads();                                               // B3: nu (and hg) visible
         stamp(0);
-        prod_At(nu, dvec, hg, true);                                   // d = H x + g + A' nu   (own columns)
+        prod_At(YES, YES, nu, dvec, true);                             // d = H x + g + A' nu   (own columns)
         stamp(1);
         __syncthreads();                                               // B1: d visible
         stamp(2);
         {
             float s[KR];
             prod_K(dvec, s);                                           // K d
-            if (cc == 0) {
+            if (cc == 0) {                                             // rows >= CW of the group: zero rows of K, padding slots
 #pragma unroll
-                for (int r = 0; r < KR; ++r)
-                    if (KR * rr + r < CW) {
-                        const int j = CW * wave + KR * rr + r;
-                        const float dx = -s[r];
-                        const double xn = x64[j] + (double)dx;
-                        x64[j] = xn;
-                        dxv[j] = dx;
-                        xin[j] = (float)xn;
-                    }
+                for (int r = 0; r < KR; ++r) {
+                    const int j = SW * wave + KR * rr + r;
+                    const float dx = -s[r];
+                    const double xn = x64[j] + (double)dx;
+                    x64[j] = xn;
+                    dxv[j] = dx;
+                    xin[j] = (float)xn;
+                    if (KR * rr + r < CW) xnat[CW * wave + KR * rr + r] = (float)xn;   // natural order: real columns only
+                }
             }
         }
         stamp(3);
@@ -416,7 +462,6 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         stamp(4);
         __syncthreads();                                               // B2: partials and x visible
         stamp(5);
-        prod_H();                                                      // H x of the new x (needed next iteration)
         stamp(6);
         iters = k;
         const bool check = (a.mode == 0) && ((k % a.check_interval) == 0);    // reluqpth.py:218 (Q3 fixed)
@@ -427,6 +472,9 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
             row_pass(false, true, false);
             const int ri_before = ri;
             rho_est = residuals(rho_est, pri, dua);                    // :220 (Q4: carried estimate)
+            rho_est = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rho_est)));
+            pri = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pri)));
+            dua = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dua)));
             if (rho_est > (float)a.rhos[ri] * tolT && ri < a.nrho - 1)          // :223
                 ri += 1;
             else if (rho_est < (float)a.rhos[ri] / tolT && ri > 0)              // :226
@@ -454,7 +502,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
 
     __syncthreads();
     if (a.mode == 1) {                                                 // iterate-only: keep the state
-        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[i];
+        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[SW * (i / CW) + i % CW];
         for (int i = tid; i < m; i += NT) {
             a.z[(size_t)b * m + i] = z64[i];
             a.lam[(size_t)b * m + i] = lam64[i];
@@ -465,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
 
     // objective 1/2 x'Hx + g'x (compute_J :320-322)
     double jp = 0.0;
-    if (tid < N) jp = (double)(xin[tid] * (0.5f * hx[tid] + gT[tid]));
+    if (tid < ND) jp = (double)(xin[tid] * (0.5f * hx[tid] + gT[tid]));
     for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
     if (lane == 0) redd[wave] = jp;
     __syncthreads();
@@ -482,7 +530,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
     }
 
     // ---- update_results (reluqpth.py:278-305)
-    if (a.out_x) for (int i = tid; i < n; i += NT) ((float*)a.out_x)[(size_t)b * n + i] = (float)x64[i];
+    if (a.out_x) for (int i = tid; i < n; i += NT) ((float*)a.out_x)[(size_t)b * n + i] = (float)x64[SW * (i / CW) + i % CW];
     if (a.out_z) for (int i = tid; i < m; i += NT) ((float*)a.out_z)[(size_t)b * m + i] = (float)z64[i];
     if (a.out_lam) for (int i = tid; i < m; i += NT) ((float*)a.out_lam)[(size_t)b * m + i] = (float)lam64[i];
     if (tid == 0) {
@@ -495,7 +543,7 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         if (a.info.obj_val) a.info.obj_val[b] = obj;
     }
     if (a.warm_starting) {                                             // state + rho index persist (:304)
-        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[i];
+        for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[SW * (i / CW) + i % CW];
         for (int i = tid; i < m; i += NT) {
             a.z[(size_t)b * m + i] = z64[i];
             a.lam[(size_t)b * m + i] = lam64[i];
@@ -515,12 +563,12 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
 // Lane-linear images written once at setup:
 //   Apack[mat][pair = rp*CQ + c][t][2]      = A[RB*pl + 2rp + h][CW*w + CQ*q + c]
 //   Kpack[mat][j][pair = kp*KC + c][t][2]   = K_j[CW*w + KR*rr + 2kp + h][KC*cc + c]   (0 when KR*rr + 2kp + h >= CW)
-//   Hpack[mat][u][t][4]                     = pairs 2u, 2u+1 of H in the K layout
+//   Hpack[mat][c][t][4]                     = H[HR*pl + 0..3][CW*w + CQ*q + c]
 template <class C>
 __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
                             float* __restrict__ Hpack) {
-    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU;
+    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR, HE2 = C::HE2;
     const int mat = blockIdx.y;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
@@ -534,13 +582,12 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
             Ap[((size_t)pair * NT + t) * 2 + h] = (r < m && c < n) ? Am[(size_t)r * ldn + c] : 0.f;
         }
         float* Hp = Hpack + (size_t)mat * HU * NT * 4;
-        for (int e = 0; e < KE2 * 2; ++e) {
-            const int pair = e >> 1, h = e & 1;
-            const int lr = KR * rr + 2 * (pair / KC) + h;
-            const int r = CW * w + lr, c = KC * cc + pair % KC;
-            // H[r][c] = Ht[c][r]
-            Hp[((size_t)(pair >> 1) * NT + t) * 4 + (pair & 1) * 2 + h] = (lr < CW && r < n && c < n) ? Hm[(size_t)c * ldn + r] : 0.f;
-        }
+        for (int c0 = 0; c0 < CQ; ++c0)                                // unit c0 = (H[HR*pl + 0..3][col(c0)]) : one b128 per column
+            for (int h = 0; h < HR; ++h) {
+                const int r = HR * pl + h, c = CW * w + CQ * q + c0;
+                // H[r][c] = Ht[c][r]
+                Hp[((size_t)c0 * NT + t) * 4 + h] = (r < n && c < n) ? Hm[(size_t)c * ldn + r] : 0.f;
+            }
     } else {
         const int j = blockIdx.x - 1;
         const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
