@@ -85,6 +85,9 @@ struct Res2Cfg {
     static constexpr int HE2 = HP * CQ;          // H float2 pairs per thread
     static constexpr int HU = HE2 / 2;           // H 16-byte units per thread
     static constexpr int H1 = (CQ + 1) / 2, H2 = (H1 + 1) / 2;
+    // workgroups per CU the register budget is shaped for (one wave per SIMD each): 2 for the big tile, up to 8 otherwise
+    static constexpr int MATREGS = 2 * (RP * CQ + KP * KC);        // VGPRs pinned by A and K; ~90 more are working registers
+    static constexpr int WAVES_PER_SIMD = (MATREGS > 100) ? 2 : ((MATREGS > 30) ? 3 : 4);
     static_assert(RB % 2 == 0 && KR % 2 == 0 && HP == 2 && HU == CQ && PL * HR >= N, "row pairs");
     static_assert(8 * KR >= CW && 8 * KC >= N && M <= 2 * NT && KC == CQ && NQ == 2, "tile shape");
     static constexpr size_t lds_bytes() {
@@ -99,7 +102,7 @@ struct Res2Cfg {
 // DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles wave 0 spends
 // in each segment of the iteration into `dbg` (never read by the kernel; never timed as the product).
 template <class C, bool DIAG>
-__global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* __restrict__ Apack,
+__global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs a, const float* __restrict__ Apack,
                                                       const float* __restrict__ Kpack,
                                                       const float* __restrict__ Hpack, unsigned long long* dbg) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, NW = C::NW, RP = C::RP, KP = C::KP;
@@ -442,16 +445,22 @@ __global__ void __launch_bounds__(256, 2) k_admm_res2(SolveArgs a, const float* 
         {
             float s[KR];
             prod_K(dvec, s);                                           // K d
-            if (cc == 0) {                                             // rows >= CW of the group: zero rows of K, padding slots
+            if (cc == 0) {                 // this lane owns slots j..j+3 (rows >= CW of the group: zero rows of K, padding slots)
+                static_assert(KR == 4 || KR == 2, "vectorised x update");
+                const int j = SW * wave + KR * rr;
+                double2* xp = (double2*)(x64 + j);
+                f2* xn2 = (f2*)(xnat + CW * wave + KR * rr);                   // natural order: real columns only
 #pragma unroll
-                for (int r = 0; r < KR; ++r) {
-                    const int j = SW * wave + KR * rr + r;
-                    const float dx = -s[r];
-                    const double xn = x64[j] + (double)dx;
-                    x64[j] = xn;
-                    dxv[j] = dx;
-                    xin[j] = (float)xn;
-                    if (KR * rr + r < CW) xnat[CW * wave + KR * rr + r] = (float)xn;   // natural order: real columns only
+                for (int hlf = 0; hlf < KR / 2; ++hlf) {
+                    double2 xa = xp[hlf];
+                    const f2 dx = {-s[2 * hlf], -s[2 * hlf + 1]};
+                    xa.x += (double)dx.x;
+                    xa.y += (double)dx.y;
+                    xp[hlf] = xa;
+                    const f2 xf = {(float)xa.x, (float)xa.y};
+                    ((f2*)(dxv + j))[hlf] = dx;
+                    ((f2*)(xin + j))[hlf] = xf;
+                    if (KR * rr + 2 * hlf + 1 < CW) xn2[hlf] = xf;
                 }
             }
         }
@@ -602,35 +611,62 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
 }
 
 // ------------------------------------------------------------------------------ host side
-typedef Res2Cfg<10, 13, 4, 13> Cfg2C2;     // n <= 104, m <= 320
+typedef Res2Cfg<10, 13, 4, 13> Cfg2C2;     // n <= 104, m <= 320   (BASELINE: n = 100, m = 300)
+typedef Res2Cfg<2, 4, 2, 4> Cfg2C4;        // n <= 32,  m <= 64    (BASELINE config 4: n = 32, m = 64)
+typedef Res2Cfg<4, 7, 2, 7> Cfg2M;         // n <= 56,  m <= 128
 
-bool rqp_res2_fits(const rqp_handle* h) { return h->esz == 4 && h->n <= Cfg2C2::N && h->m <= Cfg2C2::M; }
-
-void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
-    *a_elems = (size_t)h->nmat * Cfg2C2::AE2 * Cfg2C2::NT * 2;
-    *k_elems = (size_t)h->nmat * h->nrho * Cfg2C2::KE2 * Cfg2C2::NT * 2;
-    *h_elems = (size_t)h->nmat * Cfg2C2::HU * Cfg2C2::NT * 4;
+static int res2_pick(const rqp_handle* h) {            // smallest tile that holds the problem; -1: none
+    if (h->esz != 4) return -1;
+    if (h->n <= Cfg2C4::N && h->m <= Cfg2C4::M) return 0;
+    if (h->n <= Cfg2M::N && h->m <= Cfg2M::M) return 1;
+    if (h->n <= Cfg2C2::N && h->m <= Cfg2C2::M) return 2;
+    return -1;
 }
 
-hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
+bool rqp_res2_fits(const rqp_handle* h) { return res2_pick(h) >= 0; }
+
+template <class C>
+static void pack_elems_t(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
+    *a_elems = (size_t)h->nmat * C::AE2 * C::NT * 2;
+    *k_elems = (size_t)h->nmat * h->nrho * C::KE2 * C::NT * 2;
+    *h_elems = (size_t)h->nmat * C::HU * C::NT * 4;
+}
+void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
+    switch (res2_pick(h)) {
+        case 0: pack_elems_t<Cfg2C4>(h, a_elems, k_elems, h_elems); break;
+        case 1: pack_elems_t<Cfg2M>(h, a_elems, k_elems, h_elems); break;
+        default: pack_elems_t<Cfg2C2>(h, a_elems, k_elems, h_elems); break;
+    }
+}
+
+template <class C>
+static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
     dim3 grid(1 + h->nrho, h->nmat);
-    k_pack_res2<Cfg2C2><<<grid, Cfg2C2::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
-                                                      (const float*)h->K, h->Apack, h->Kpack, h->Hpack);
+    k_pack_res2<C><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack);
     return hipGetLastError();
 }
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
+    switch (res2_pick(h)) {
+        case 0: return pack_t<Cfg2C4>(h, s);
+        case 1: return pack_t<Cfg2M>(h, s);
+        default: return pack_t<Cfg2C2>(h, s);
+    }
+}
 
-hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    const size_t lds = Cfg2C2::lds_bytes();
-    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<Cfg2C2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <class C>
+static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = C::lds_bytes();
+    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (const char* dbg = getenv("RQP_DEBUG")) {
         if (dbg[0] == '1') {
             int nb = -1;
-            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<Cfg2C2, false>, Cfg2C2::NT, lds);
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false>, C::NT, lds);
             hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<Cfg2C2, false>);
-            fprintf(stderr, "[rqp] k_admm_res2: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", nb, (int)oe, lds,
-                    fa.numRegs, (size_t)fa.localSizeBytes);
+            (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<C, false>);
+            fprintf(stderr, "[rqp] k_admm_res2<%d,%d,%d,%d>: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", C::RB, C::CQ,
+                    C::KR, C::KC, nb, (int)oe, lds, fa.numRegs, (size_t)fa.localSizeBytes);
         }
     }
     if (const char* dg = getenv("RQP_DIAG")) {
@@ -638,13 +674,13 @@ hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStr
             unsigned long long* dbg = nullptr;
             const size_t cnt = (size_t)h->B * 4 * 10;
             if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
-            (void)hipFuncSetAttribute((const void*)k_admm_res2<Cfg2C2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            k_admm_res2<Cfg2C2, true><<<h->B, Cfg2C2::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
+            (void)hipFuncSetAttribute((const void*)k_admm_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k_admm_res2<C, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> hbuf(cnt);
             (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
             (void)hipFree(dbg);
-            static const char* names[9] = {"B3 wait", "A'nu", "B1 wait", "Kd+x", "A dx", "B2 wait", "H x", "rows", "check"};
+            static const char* names[9] = {"B3 wait", "A'nu+Hx", "B1 wait", "Kd+x", "A dx", "B2 wait", "-", "rows", "check"};
             for (int w = 0; w < 4; ++w) {
                 double tot[9] = {0}, its = 0;
                 for (int b = 0; b < h->B; ++b) {
@@ -659,6 +695,13 @@ hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStr
             return hipGetLastError();
         }
     }
-    k_admm_res2<Cfg2C2, false><<<h->B, Cfg2C2::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr);
+    k_admm_res2<C, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr);
     return hipGetLastError();
+}
+hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    switch (res2_pick(h)) {
+        case 0: return solve_t<Cfg2C4>(h, a, s);
+        case 1: return solve_t<Cfg2M>(h, a, s);
+        default: return solve_t<Cfg2C2>(h, a, s);
+    }
 }

@@ -261,7 +261,7 @@ def test_g7_K(golden, prec, rtol):
 
 # ------------------------------------------------------------ batch == per-instance
 @pytest.mark.parametrize("prec", [torch.float64, torch.float32])
-@pytest.mark.parametrize("n,n_eq,n_ineq,B", [(10, 5, 15, 33), (32, 8, 56, 40), (7, 2, 4, 16)])
+@pytest.mark.parametrize("n,n_eq,n_ineq,B", [(10, 5, 15, 33), (32, 8, 56, 40), (7, 2, 4, 16), (50, 10, 110, 12)])
 def test_batch_matches_oracle(prec, n, n_eq, n_ineq, B):
     H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=100, feasible=True)
     m = _model(H, g, A, l, u, precision=prec)
