@@ -77,7 +77,9 @@ struct Res2Cfg {
     static constexpr int CW = NQ * CQ;           // columns per wave
     static constexpr int N = NW * CW;            // padded columns
     static constexpr int M = PL * RB;            // padded rows
-    static constexpr int SW = 8 * KR;            // vector slots per wave (>= CW): column j lives at SW*(j/CW) + j%CW
+    // vector slots: column j lives at SW*(j/CW) + j%CW.  Each wave uses 8*KR >= CW slots; the pitch SW adds 4 so that
+    // the 8 column groups a wave reads together (SW*(cc>>1) + CQ*(cc&1)) fall in distinct LDS banks
+    static constexpr int SW = 8 * KR + 4;
     static constexpr int ND = NW * SW;           // padded vector length
     static constexpr int AE2 = RP * CQ;          // A float2 pairs per thread
     static constexpr int KE2 = KP * KC;          // K / H float2 pairs per thread
