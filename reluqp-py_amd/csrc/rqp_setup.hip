@@ -202,8 +202,80 @@ __global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
     }
 }
 
+// Fast path for n <= 128: same in-place Gauss-Jordan, but thread t owns column c = t & (CN-1) of the row slice
+// rs = t / CN (no integer division in the sweep, row k of the step in a register, column k broadcast from LDS).
+// CN = 64 or 128 columns (power of two >= n).
+template <typename T, int CN>
+__global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int RS = 256 / CN;                 // row slices
+    const int n = a.n;
+    const int mat = blockIdx.x / a.nrho, j = blockIdx.x % a.nrho;
+    double* colb = (double*)smem_raw;            // [n] column k before the sweep
+    double* rowb = colb + n;                     // [n] scaled pivot row
+    double* M = rowb + n;                        // [n][n] row-major (consecutive c -> consecutive banks); 2 WGs/CU at n = 100
+    const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
+    const double* G = a.G + (size_t)mat * n * n;
+    const double rho = a.rhos[j];
+    const int tid = threadIdx.x, c = tid & (CN - 1), rs = tid / CN;
+    const bool cin = c < n;
+    if (cin)
+        for (int r = rs; r < n; r += RS) {
+            const double hs = 0.5 * ((double)Ht[(size_t)r * a.ldn + c] + (double)Ht[(size_t)c * a.ldn + r]);
+            M[r * n + c] = hs + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
+        }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double p = 1.0 / M[k * n + k];
+        // column k (before the sweep) -> colb ; scaled row k -> rowb (written by the slice that owns row k)
+        if (tid < n) colb[tid] = M[tid * n + k];
+        if (cin && rs == (k & (RS - 1))) rowb[c] = (c == k) ? p : M[k * n + c] * p;
+        __syncthreads();
+        if (cin) {
+            const double rb = rowb[c];
+            const double f = (c == k) ? 0.0 : 1.0;            // column k: M[r][k] = -colb[r] * p  (rb = p there)
+            // rows in batches of UB: all loads of a batch are issued before its FMAs (LDS latency overlaps)
+            constexpr int UB = 8;
+            for (int r0 = rs; r0 < n; r0 += RS * UB) {
+                double mv[UB], cb[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int r = r0 + u * RS;
+                    const bool ok = r < n;
+                    mv[u] = ok ? M[r * n + c] : 0.0;
+                    cb[u] = ok ? colb[r] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) mv[u] = fma(-cb[u], rb, f * mv[u]);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int r = r0 + u * RS;
+                    if (r < n) M[r * n + c] = mv[u];
+                }
+            }
+            if (rs == (k & (RS - 1))) M[k * n + c] = rb;      // row k: the scaled pivot row (same thread as the sweep)
+        }
+        __syncthreads();
+    }
+    T* K = (T*)a.K + ((size_t)mat * a.nrho + j) * n * a.ldn;
+    for (int r = rs; r < n; r += RS)
+        if (c < a.ldn) K[(size_t)r * a.ldn + c] = cin ? (T)(0.5 * (M[r * n + c] + M[c * n + r])) : T(0);
+}
+
+template <typename T, int CN>
+static hipError_t launch_factor_fast(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    const size_t lds = (2 * (size_t)h->n + (size_t)h->n * h->n) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)k_factor_fast<T, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_factor_fast<T, CN><<<h->nmat * h->nrho, 256, lds, s>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     const int n = h->n;
+    if (n <= 64) return h->esz == 4 ? launch_factor_fast<float, 64>(h, a, s) : launch_factor_fast<double, 64>(h, a, s);
+    if (n <= 128 && h->ldn <= 128)
+        return h->esz == 4 ? launch_factor_fast<float, 128>(h, a, s) : launch_factor_fast<double, 128>(h, a, s);
     const size_t lds_need = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);
     const bool lds_mode = lds_need <= 160 * 1024 - 512;
     const int grid = h->nmat * h->nrho;
