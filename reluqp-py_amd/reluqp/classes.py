@@ -103,7 +103,7 @@ class Info(object):
                  rho_estimate=None,
                  ):
         self.iter = iter
-        self.status = status
+        self._status = status
         self.obj_val = obj_val
         self.pri_res = pri_res
         self.dua_res = dua_res
@@ -114,6 +114,19 @@ class Info(object):
         self.rho_estimate = rho_estimate
         self.status_code = None
         self.rho_ind = None
+
+    # batched solves keep the exit codes on the device; the list of strings ("solved" /
+    # "max_iters_reached", reluqpth.py:236,245) is built on first access (one device->host copy)
+    @property
+    def status(self):
+        if self._status is None and self.status_code is not None and hasattr(self.status_code, "cpu"):
+            from reluqp._cabi import STATUS_STR
+            self._status = [STATUS_STR[int(c)] for c in self.status_code.cpu().tolist()]
+        return self._status
+
+    @status.setter
+    def status(self, value):
+        self._status = value
 
 
 class Results(object):

@@ -271,7 +271,7 @@ class ReLU_QP(object):
             self.results.x, self.results.z, self.results.y = x, z, lam
             info.iter = ints[0]
             info.status_code = ints[1]
-            info.status = [_cabi.STATUS_STR[int(c)] for c in ints[1].cpu().tolist()]
+            info.status = None            # materialised lazily from status_code (classes.Info.status)
             info.rho_ind = ints[2]
             info.pri_res, info.dua_res = dbls[0].to(prec), dbls[1].to(prec)
             info.rho_estimate, info.obj_val = dbls[2].to(prec), dbls[3].to(prec)

@@ -39,7 +39,8 @@ def _model(H, g, A, l, u, precision=torch.float64, generic=False, **kw):
         m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
     finally:
         os.environ["RQP_FORCE_GENERIC"] = "0"
-    assert m.kernel.startswith("generic" if (generic or precision == torch.float64) else "resident")
+    if generic or precision == torch.float64:
+        assert m.kernel == "generic"
     return m
 
 
@@ -310,6 +311,32 @@ def test_resident_equals_generic_fp32():
     np.testing.assert_allclose(_np(rr.x)[~same], _np(rg.x)[~same], rtol=0, atol=1e-2 * scale)   # eps_abs-level agreement
     assert all(s == "solved" for s in rg.info.status)
     assert all(s == "solved" for s in rr.info.status)
+
+
+@pytest.mark.parametrize("n,n_eq,n_ineq,kernel", [
+    (32, 8, 56, "resident2"),      # exactly the small tile (n=32, m=64)
+    (33, 8, 57, "resident2"),      # one past it -> mid tile
+    (56, 14, 114, "resident2"),    # exactly the mid tile (n=56, m=128)
+    (57, 14, 115, "resident2"),    # one past it -> big tile
+    (104, 26, 294, "resident2"),   # exactly the big tile (n=104, m=320)
+    (105, 26, 294, "generic"),     # one past it -> streaming kernel
+    (100, 25, 296, "generic"),     # m = 321 > 320 -> streaming kernel
+])
+def test_tile_boundaries_fp32(n, n_eq, n_ineq, kernel):
+    """Padding paths of the resident tiles: sizes on and just past every tile limit give oracle results."""
+    B = 3
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=900 + n, feasible=True)
+    m = _model(H, g, A, l, u, precision=torch.float32)
+    assert m.kernel == kernel
+    res = m.solve()
+    ref = O.solve_batch(H, g, A, l, u, form="factored")
+    it = res.info.iter.cpu().numpy()
+    assert all(s == "solved" for s in res.info.status)
+    assert np.all(np.abs(it - ref["iter"]) <= 75)                  # marginal checks may shift the exit (see above)
+    same = it == ref["iter"]
+    assert same.sum() >= 2
+    np.testing.assert_allclose(_np(res.x)[same], ref["x"][same], rtol=0, atol=5e-5 * np.abs(ref["x"]).max())
+    np.testing.assert_allclose(_np(res.x), xs, rtol=0, atol=2e-2 * max(1.0, np.abs(xs).max()))   # planted optimum
 
 
 @pytest.mark.parametrize("prec", [torch.float64, torch.float32])

@@ -1,0 +1,53 @@
+"""Linear-MPC path on the GPU: shared (H, A) batches through the C-ABI against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reluqp_oracle as O
+from reluqp import mpc
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(form, nx=6, nu=2, N=10, seed=7, B=24):
+    Ad, Bd = mpc.random_plant(nx, nu, seed=seed)
+    ctl = mpc.LinearMPC(Ad, Bd, np.eye(nx), 0.1 * np.eye(nu), N, u_max=0.4, x_max=8.0, form=form,
+                        device=torch.device("cuda:0"), precision=torch.float32, eps_abs=1e-3)
+    x0 = 1.5 * np.random.RandomState(seed).randn(B, nx)
+    return ctl, x0
+
+
+@pytest.mark.parametrize("form", ["condensed", "sparse"])
+def test_mpc_batch_matches_oracle(form):
+    import reluqp.reluqpth as reluqpth
+    ctl, x0 = _setup(form)
+    g, l, u = ctl.qp_vectors(x0)
+    model = reluqpth.ReLU_QP()
+    model.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, eps_abs=1e-3)
+    assert model.QP.shared_mats and model.kernel.startswith("resident")
+    res = model.solve()
+    ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", eps_abs=1e-3)
+    assert res.info.status == ref["status"]            # incl. any instance the reference algorithm cannot solve
+    assert np.mean([s == "solved" for s in res.info.status]) >= 0.9
+    it = res.info.iter.cpu().numpy()
+    assert np.mean(it == ref["iter"]) >= 0.85
+    same = it == ref["iter"]
+    x = res.x.cpu().double().numpy()
+    np.testing.assert_allclose(x[same], ref["x"][same], rtol=0, atol=1e-4 * max(1.0, np.abs(ref["x"]).max()))
+    u0 = ctl.first_input(x, x0)
+    assert np.all(np.abs(u0) <= 0.4 + 2e-2)                           # eps_abs-level constraint satisfaction
+
+
+def test_mpc_closed_loop_update_and_warm_start():
+    ctl, x0 = _setup("condensed", B=16)
+    xs, us, its = ctl.simulate(x0, steps=40)
+    nrm = np.linalg.norm(xs, axis=2)
+    assert np.all(nrm[-1] < 0.5 * nrm[0])                             # regulated
+    assert np.all(np.abs(us) <= 0.4 + 2e-2)
+    assert its[10:].mean() < its[0].mean()                           # warm starts pay
+    # the same loop with the float64 kernels follows the same trajectory (tolerance: eps_abs-level inputs)
+    Ad, Bd = ctl.Ad, ctl.Bd
+    ctl64 = mpc.LinearMPC(Ad, Bd, np.eye(6), 0.1 * np.eye(2), 10, u_max=0.4, x_max=8.0, form="condensed",
+                          device=torch.device("cuda:0"), precision=torch.float64, eps_abs=1e-3)
+    xs64, us64, _ = ctl64.simulate(x0, steps=40)
+    assert np.abs(xs64 - xs).max() < 5e-2 * np.abs(xs).max()
