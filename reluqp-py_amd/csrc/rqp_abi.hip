@@ -67,7 +67,7 @@ int argmin_abs(const std::vector<double>& r, double v) {   // np.argmin(np.abs(r
 void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
-                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack};
+                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -75,10 +75,12 @@ void free_ws(rqp_handle* h) {
     h->is_setup = false;
     h->resident = false;
     h->res_kind = 0;
+    h->use_mfma = false;
     h->kernel_name = "generic";
 }
 
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    if (h->use_mfma && a.mode == 0) return rqp_launch_solve_mfma(h, a, s);
     if (h->resident && h->res_kind == 2) return rqp_launch_solve_res2(h, a, s);
     if (h->resident) return rqp_launch_solve_resident(h, a, s);
     return rqp_launch_solve_generic(h, a, s);
@@ -219,6 +221,15 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         h->resident = true;
         h->res_kind = want_v1 ? 1 : 2;
         h->kernel_name = want_v1 ? "resident" : "resident2";
+    }
+    // shared-(H,A) batches large enough to fill the chip with 16-instance tiles go to the MFMA kernel
+    const char* mf = getenv("RQP_MFMA");                  // "0": never, "1": whenever it fits
+    h->use_mfma = rqp_mfma_fits(h) && !(force && force[0] == '1') && !(mf && mf[0] == '0') &&
+                  (h->B >= 1024 || (mf && mf[0] == '1'));
+    if (h->use_mfma) {
+        HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
+        HIP_TRY(h, rqp_launch_pack_mfma(h, s));
+        h->kernel_name = "mfma";
     }
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)

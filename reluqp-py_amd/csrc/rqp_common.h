@@ -46,6 +46,8 @@ struct rqp_handle {
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
     bool resident = false;
     int res_kind = 0;             // 1: rqp_resident.hip (row-block layout), 2: rqp_resident2.hip (column block per wave)
+    bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
+    float* W1img = nullptr;       // lane-linear GEMM1 operand image ([A; H'] as MFMA A-operands)
 
     const char* kernel_name = "generic";
     std::string err;
@@ -99,5 +101,10 @@ bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+
+bool rqp_mfma_fits(const rqp_handle* h);
+size_t rqp_mfma_img_elems(const rqp_handle* h);
+hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 static inline int rqp_round_up(int v, int q) { return (v + q - 1) / q * q; }

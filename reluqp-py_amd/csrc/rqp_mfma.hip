@@ -1,0 +1,623 @@
+// rqp_mfma.hip -- ADMM hot loop for batches that SHARE (H, A) (linear MPC): the batch is the N
+// dimension of fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector rate, one
+// instruction = 1024 MACs instead of 64 -- the instruction overhead of the per-instance kernels disappears).
+//
+// One 256-thread workgroup (4 waves, one per SIMD, up to 512 VGPRs each) iterates a TILE of 16 instances:
+//   GEMM1  d  = [A; H']' [nu; x] + g     (n x 16)   K split over the 4 waves, partials meet in LDS
+//   GEMM2  dx = -K_j d                   (n x 16)   K split; per-column choice of K_j (each instance has its own
+//                                                   rho index): one masked pass per distinct index in the tile
+//   GEMM3  A dx                          (m x 16)   M split: wave w owns m/4 rows and their row state
+// The matrices are MFMA A-operands.  [A; H'] (GEMM1) and A (GEMM3) stay in registers for the whole solve: 225 per lane,
+// in the accumulator half of the unified register file (AGPRs, pinned with empty asm constraints -- left alone hipcc
+// keeps MFMA sources in arch VGPRs and spills them).  K_j blocks (25 per lane) sit in two tagged VGPR blocks that
+// refill from L2.  All operands are read from lane-linear images packed at setup (k_pack_mfma), so every load is one
+// coalesced 256 B row per wave.  B-operands (nu, x, d, dx) pass through LDS in [k][16] layout.  Per-instance state
+// lives in registers in the MFMA D layout (lane = instance column, 4 rows per 16x16 tile): z, lam in float32 and A x
+// as a float-float pair (the role float64 plays in the other kernels: only A x needs the extra bits, DESIGN.md
+// section 2); l, u, g wait in LDS.
+// Register-allocation notes (hipcc 7.2): rare-path sizes/offsets go through opaque copies, otherwise LICM hoists
+// hundreds of loop-invariant addresses and predicates out of the solve loop and the kernel spills.
+// Same recurrence, check logic and quirk dispositions as k_admm_generic (rqp_admm.hip); reference line citations there.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rqp_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB_, int MBW_>
+struct MfmaCfg {
+    static constexpr int NB = NB_, MBW = MBW_;        // n tiles of 16 ; m tiles of 16 per wave
+    static constexpr int NT = 256, NW = 4, TB = 16;
+    static constexpr int MB = NW * MBW;
+    static constexpr int NP = 16 * NB, MP = 16 * MB, KT = MP + NP;
+    static constexpr int KS1 = KT / 4 / NW;           // k-steps of GEMM1 per wave
+    static constexpr int KS2 = NB;                    // k-steps of GEMM2 per wave   (NP/4/NW)
+    static constexpr int KS3 = NP / 4;                // k-steps of GEMM3 (every wave runs all of them)
+    // lane-linear operand images (floats): W1 [NW][KS1][NB][64] | W3 [NW][MBW][KS3][64] | K [nrho][NW][KS2][NB][64]
+    static constexpr size_t W1_ELEMS = (size_t)NW * KS1 * NB * 64, W3_ELEMS = (size_t)NW * MBW * KS3 * 64;
+    static constexpr size_t KJ_ELEMS = (size_t)NW * KS2 * NB * 64;
+    static constexpr size_t lds_floats() {
+        return (size_t)KT * 16 + 2 * NP * 16 + NW * NP * 16 + 3 * MP * 16 + NB * NT + NP * 16 + NW * 16 * 4 + 16 * 16 * 8 + 64 + 8 * 16;
+    }
+};
+
+__device__ __forceinline__ float nanmaxf(float a, float b) {          // NaN-propagating max (torch semantics)
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+
+// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles each wave spends per segment.
+template <class C, bool DIAG>
+__global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* __restrict__ img, unsigned long long* __restrict__ dbg) {
+    constexpr int NB = C::NB, MBW = C::MBW, NT = C::NT, NW = C::NW, NP = C::NP, MP = C::MP, KT = C::KT;
+    constexpr int KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* V1 = sm;                          // [KT][16]  rows 0..MP-1: nu (lam / 0 at a check); rows MP..: x (0 at a check)
+    float* V2 = V1 + KT * 16;                // [NP][16]  d
+    float* V3 = V2 + NP * 16;                // [NP][16]  dx
+    float* part = V3 + NP * 16;              // [NW][NP][16] wave partials (GEMM1 / GEMM2)
+    float* LB = part + NW * NP * 16;         // [4 MBW][NT] l of the lane's own rows (lane-linear: conflict-free, owner-only)
+    float* UB = LB + MP * 16;                // [4 MBW][NT] u
+    float* ZL = UB + MP * 16;                // [4 MBW][NT] low word of the float-float A x
+    float* T3 = ZL + MP * 16;                // [NB][NT]    A' lam of the pending check
+    float* GV = T3 + NB * NT;                // [NP][16] g
+    float* red = GV + NP * 16;               // [NW][16][4] row-side maxima per (wave, instance)
+    float* rr = red + NW * 16 * 4;           // [16 rowgroups][16][8] column-side maxima per (row group, instance)
+    float* rhosf = rr + 16 * 16 * 8;         // [64] rho ladder
+    float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 1 settings, 4 ri (int), 5 done (int), 7 newly (int)
+    int* inst_i = (int*)inst;
+
+    const int n = a.n, m = a.m, ldn = a.ldn;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i16 = lane & 15, kq = lane >> 4;       // MFMA lane coordinates
+    const int cj = tid & 15, rg = tid >> 4;          // column-owner coordinates: instance cj, rows rg + 16 e
+    const int b0 = blockIdx.x * 16;                  // first instance of the tile
+    const bool inst_ok = (b0 + i16) < a.B;           // this lane's MFMA column is a real instance
+    const bool cinst_ok = (b0 + cj) < a.B;
+    const size_t bi = (size_t)(b0 + i16), bc = (size_t)(b0 + cj);
+
+    // ---- resident A-operands (images: see MfmaCfg) -------------------------------------------------------------------
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float aw1[KS1][NB];              // GEMM1: S[4 (KS1 wave + s) + kq][16 t + i16],  S = [A (MP rows); H' (NP rows)]
+    {
+        const float* w1 = img + (size_t)wave_u * KS1 * NB * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                aw1[s][t] = w1[(s * NB + t) * 64];
+                asm volatile("" : "+a"(aw1[s][t]));          // resident MFMA A-operands live in the accumulator half (AGPRs)
+            }
+    }
+    float a3[MBW][KS3];              // GEMM3: A[16 (MBW wave + tl) + i16][4 s + kq]
+    {
+        const float* w3 = img + C::W1_ELEMS + (size_t)wave_u * MBW * KS3 * 64 + lane;
+#pragma unroll
+        for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) {
+                a3[tl][s] = w3[(tl * KS3 + s) * 64];
+                asm volatile("" : "+a"(a3[tl][s]));
+            }
+    }
+    // GEMM2: K_j[16 t + i16][4 (KS2 wave + s) + kq] in two tagged VGPR blocks
+    const float* kimg = img + C::W1_ELEMS + C::W3_ELEMS + (size_t)wave_u * KS2 * NB * 64;
+    float kb0[KS2][NB], kb1[KS2][NB];
+    int ktag0 = -1, ktag1 = -1;
+
+    // ---- per-instance scalars and vectors -----------------------------------------------------------------------
+    for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
+    if (tid < 16) {
+        const bool ok = (b0 + tid) < a.B;
+        inst_i[4 * 16 + tid] = a.rho_ind[ok ? b0 + tid : b0];      // padding columns mirror instance b0 (no extra K block)
+        inst_i[5 * 16 + tid] = ok ? 0 : 1;                         // padding columns start "done"
+        inst_i[7 * 16 + tid] = 0;
+    }
+    // row state (wave w owns rows [16 MBW w, 16 MBW (w+1)); lane: instance i16, rows 16 T + 4 kq + r)
+    float zh[MBW][4], zz[MBW][4], lm[MBW][4];           // (the low word of A x lives in ZL)
+    unsigned eqmask = 0;                                  // bit (4 tl + r): equality row (rho * 1e3)
+#pragma unroll
+    for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * (MBW * wave + tl) + 4 * kq + r;
+            const bool ok = inst_ok && row < m;
+            zh[tl][r] = 0.f;
+            ZL[(4 * tl + r) * NT + tid] = 0.f;
+            zz[tl][r] = ok ? (float)a.z[bi * m + row] : 0.f;
+            lm[tl][r] = ok ? (float)a.lam[bi * m + row] : 0.f;
+            LB[(4 * tl + r) * NT + tid] = ok ? ((const float*)a.l)[bi * m + row] : 0.f;
+            UB[(4 * tl + r) * NT + tid] = ok ? ((const float*)a.u)[bi * m + row] : 0.f;
+            const float cv = (row < m) ? ((const float*)a.c)[(inst_ok ? bi : 0) * m + row] : 1.f;
+            if (cv > 1.f) eqmask |= 1u << (4 * tl + r);
+        }
+    // column state: x of rows rg + 16 e of instance cj (g in LDS)
+    float xr[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int row = rg + 16 * e;
+        const bool ok = cinst_ok && row < n;
+        xr[e] = ok ? (float)a.x[bc * n + row] : 0.f;
+        GV[row * 16 + cj] = ok ? ((const float*)a.g)[bc * n + row] : 0.f;
+        V1[(MP + row) * 16 + cj] = xr[e];
+        V3[row * 16 + cj] = xr[e];                        // A x of the incoming state: GEMM3 on x
+    }
+    __syncthreads();
+    if (tid < 16) inst[0 * 16 + tid] = rhosf[inst_i[4 * 16 + tid]];               // rho_est = rhos[rho_ind]  (:211)
+    int ri_l = inst_i[4 * 16 + i16];                      // rho index of this lane's MFMA column
+    float rho_ne, rho_eq, inv_ne, inv_eq;                 // rho of this lane's instance (plain / equality rows) and inverses
+    auto set_rho = [&]() __attribute__((always_inline)) {
+        rho_ne = rhosf[ri_l];
+        rho_eq = rho_ne * 1e3f;
+        inv_ne = 1.0f / rho_ne;
+        inv_eq = 1.0f / rho_eq;
+    };
+    set_rho();
+
+    const int kmax = a.max_iter;
+    if (tid == 0) {                                       // float copies of the scalar settings, read back in the decision block
+        inst[16 + 0] = (float)a.tol;
+        inst[16 + 1] = (float)a.thr_p;
+        inst[16 + 2] = (float)a.thr_d;
+        inst[16 + 3] = (float)a.rho_min;
+        inst[16 + 4] = (float)a.rho_max;
+    }
+
+    // lam_hat and nu of the next iteration from the current state (p = A x - z)
+    auto make_nu = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rho = ((eqmask >> (4 * tl + r)) & 1u) ? rho_eq : rho_ne;
+                const float p = (zh[tl][r] - zz[tl][r]) + ZL[(4 * tl + r) * NT + tid];
+                const float lh = lm[tl][r] + rho * p;
+                lm[tl][r] = lh;
+                V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = lh + rho * p;
+            }
+    };
+
+    // The loop is a small state machine so that each GEMM has ONE call site (one copy of its operands' live ranges):
+    //   ph 0  start: GEMM3 on x -> A x of the incoming state
+    //   ph 1  iterate: GEMM1 -> d -> GEMM2 -> dx, x -> GEMM3 -> row update
+    //   ph 2  check, part 1: GEMM1 on [lam; 0] -> t3 = A' lam
+    //   ph 3  check, part 2: GEMM1 on [0; x]   -> t2 = H x ; residuals, rho moves, exits (compute_residuals :307-318)
+    int ph = 0, k = 0, to_chk = a.check_interval;         // to_chk: iterations until k is a multiple of check_interval
+    bool final_chk = false;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;                  // row-side maxima of the pending check
+
+    unsigned long long t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int seg) __attribute__((always_inline)) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0) t_acc[seg] += t - t_last;
+            t_last = t;
+        }
+    };
+    stamp(-1);
+
+    while (true) {
+        __syncthreads();
+        stamp(0);
+        if (ph != 0) {                                   // ---------------- GEMM1: wave partial of S' V1
+            f32x4 acc[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const float bv = V1[(4 * (KS1 * wave + s) + kq) * 16 + i16];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    asm volatile("" ::"a"(aw1[s][t]));              // keep the operand in its AGPR: the MFMA reads it from there
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw1[s][t], bv, acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(wave * NP + 16 * t + 4 * kq + r) * 16 + i16] = acc[t][r];
+            stamp(1);
+            __syncthreads();
+            stamp(2);
+        }
+        bool run_g3 = (ph == 0);
+        if (ph == 1) {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {                            // d = g + sum of the 4 partials (fixed order)
+                const int row = rg + 16 * e;
+                float d = GV[row * 16 + cj];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d += part[(w * NP + row) * 16 + cj];
+                V2[row * 16 + cj] = d;
+            }
+            stamp(3);
+            __syncthreads();
+            stamp(4);
+            {                                                        // dx partial = K_j d, K_j chosen per column
+                f32x4 sel[NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) sel[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float bv[KS2];
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) bv[s] = V2[(4 * (KS2 * wave + s) + kq) * 16 + i16];
+                unsigned long long todo = __ballot(lane < 16);       // one representative lane per instance column
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    const int j = __builtin_amdgcn_readlane(ri_l, src);
+                    if (j != ktag0 && j != ktag1) {                  // miss: refill a block from the L2 image of K_j
+                        // block 0 is sticky while any column of the tile still uses its K; block 1 takes the rest
+                        const bool b0_used = __ballot(ri_l == ktag0) != 0ull;
+                        const bool to0 = ktag0 < 0 || (!b0_used && ktag1 >= 0);
+                        unsigned loff = lane;
+                        asm volatile("" : "+v"(loff));               // opaque: keeps this rare path's addresses out of the loop header
+                        const float* kp = kimg + (size_t)j * C::KJ_ELEMS + loff;
+                        if (to0) {
+#pragma unroll
+                            for (int s = 0; s < KS2; ++s)
+#pragma unroll
+                                for (int t = 0; t < NB; ++t) kb0[s][t] = kp[(s * NB + t) * 64];
+                            ktag0 = j;
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < KS2; ++s)
+#pragma unroll
+                                for (int t = 0; t < NB; ++t) kb1[s][t] = kp[(s * NB + t) * 64];
+                            ktag1 = j;
+                        }
+                    }
+                    f32x4 acc[NB];
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (j == ktag0) {
+#pragma unroll
+                        for (int s = 0; s < KS2; ++s)
+#pragma unroll
+                            for (int t = 0; t < NB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb0[s][t], bv[s], acc[t], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KS2; ++s)
+#pragma unroll
+                            for (int t = 0; t < NB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb1[s][t], bv[s], acc[t], 0, 0, 0);
+                    }
+                    const bool mine = (ri_l == j);
+#pragma unroll
+                    for (int t = 0; t < NB; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sel[t][r] = mine ? acc[t][r] : sel[t][r];
+                    todo &= ~__ballot(lane < 16 && ri_l == j);
+                }
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[(wave * NP + 16 * t + 4 * kq + r) * 16 + i16] = sel[t][r];
+            }
+            stamp(5);
+            __syncthreads();
+            stamp(6);
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {                            // dx = -K d ; x += dx
+                const int row = rg + 16 * e;
+                float kd = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) kd += part[(w * NP + row) * 16 + cj];
+                const float dx = -kd;
+                xr[e] += dx;
+                V3[row * 16 + cj] = dx;
+                V1[(MP + row) * 16 + cj] = xr[e];
+            }
+            stamp(7);
+            __syncthreads();
+            stamp(8);
+            if constexpr (DIAG) t_acc[11] += 1;
+            run_g3 = true;
+        }
+        if (run_g3) {                                    // ---------------- GEMM3: (A V3)[rows of this wave][16]
+            f32x4 acc[MBW];
+#pragma unroll
+            for (int tl = 0; tl < MBW; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) {
+                const float bv = V3[(4 * s + kq) * 16 + i16];
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl) {
+                    asm volatile("" ::"a"(a3[tl][s]));          // keep the operand in its AGPR: the MFMA reads it from there
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[tl][s], bv, acc[tl], 0, 0, 0);
+                }
+            }
+            if (ph == 0) {                               // A x of the incoming state
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zh[tl][r] = acc[tl][r];
+            } else {                                     // A x += A dx ; z = clamp(A x + lam_hat / rho, l, u)
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float adx = acc[tl][r];    // float-float accumulation of A x (two-sum + renormalisation)
+                        const float sgm = zh[tl][r] + adx;
+                        const float bb = sgm - zh[tl][r];
+                        const float err = (zh[tl][r] - (sgm - bb)) + (adx - bb);
+                        const float lo = ZL[(4 * tl + r) * NT + tid] + err;
+                        const float hi = sgm + lo;
+                        const float zlo = lo - (hi - sgm);
+                        ZL[(4 * tl + r) * NT + tid] = zlo;
+                        zh[tl][r] = hi;
+                        const float irho = ((eqmask >> (4 * tl + r)) & 1u) ? inv_eq : inv_ne;
+                        const float v = hi + (zlo + lm[tl][r] * irho);
+                        const float lo_b = LB[(4 * tl + r) * NT + tid], up_b = UB[(4 * tl + r) * NT + tid];
+                        float zn = v;                    // torch.clamp: NaN stays NaN
+                        if (v < lo_b) zn = lo_b;
+                        if (v > up_b) zn = up_b;
+                        zz[tl][r] = zn;
+                    }
+                k += 1;
+                to_chk -= 1;
+            }
+            stamp(9);
+        }
+        // ---------------------------------------------------------------------------------- what comes next
+        if (ph == 0 || ph == 1) {
+            final_chk = (ph == 0) ? (kmax == 0) : (k >= kmax && to_chk != 0);
+            const bool chk = (ph == 1 && to_chk == 0) || final_chk;                       // :218 (Q3 fixed) / :243
+            if (to_chk == 0) to_chk = a.check_interval;
+            if (!chk) {
+                make_nu();
+                ph = 1;
+            } else {                                     // check part 1: V1 = [lam; 0], row-side maxima
+                v0 = 0.f; v1 = 0.f; v2 = 0.f;
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float zlo = ZL[(4 * tl + r) * NT + tid];
+                        v0 = nanmaxf(v0, fabsf((zh[tl][r] - zz[tl][r]) + zlo));
+                        v1 = nanmaxf(v1, fabsf(zh[tl][r] + zlo));
+                        v2 = nanmaxf(v2, fabsf(zz[tl][r]));
+                        V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = lm[tl][r];
+                    }
+#pragma unroll
+                for (int e = 0; e < NB; ++e) V1[(MP + rg + 16 * e) * 16 + cj] = 0.f;
+                ph = 2;
+            }
+        } else if (ph == 2) {                            // t3 = A' lam ; then V1 = [0; x]
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int row = rg + 16 * e;
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += part[(w * NP + row) * 16 + cj];
+                T3[e * NT + tid] = t;
+                V1[(MP + row) * 16 + cj] = xr[e];
+            }
+#pragma unroll
+            for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = 0.f;
+            ph = 3;
+        } else {                                         // ph == 3: t2 = H x ; residuals and decisions
+            v0 = nanmaxf(v0, __shfl_xor(v0, 16, 64)); v0 = nanmaxf(v0, __shfl_xor(v0, 32, 64));
+            v1 = nanmaxf(v1, __shfl_xor(v1, 16, 64)); v1 = nanmaxf(v1, __shfl_xor(v1, 32, 64));
+            v2 = nanmaxf(v2, __shfl_xor(v2, 16, 64)); v2 = nanmaxf(v2, __shfl_xor(v2, 32, 64));
+            if (kq == 0) {
+                red[(wave * 16 + i16) * 4 + 0] = v0;
+                red[(wave * 16 + i16) * 4 + 1] = v1;
+                red[(wave * 16 + i16) * 4 + 2] = v2;
+            }
+            float w3 = 0.f, w4 = 0.f, w5 = 0.f, w6 = 0.f, jp = 0.f;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int row = rg + 16 * e;
+                float t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t2 += part[(w * NP + row) * 16 + cj];
+                const float ge = GV[row * 16 + cj], t3 = T3[e * NT + tid];
+                w3 = nanmaxf(w3, fabsf(t2 + t3 + ge));
+                w4 = nanmaxf(w4, fabsf(t2));
+                w5 = nanmaxf(w5, fabsf(t3));
+                w6 = nanmaxf(w6, fabsf(ge));
+                jp += xr[e] * (0.5f * t2 + ge);                      // compute_J :320-322
+            }
+            rr[(rg * 16 + cj) * 8 + 3] = w3;
+            rr[(rg * 16 + cj) * 8 + 4] = w4;
+            rr[(rg * 16 + cj) * 8 + 5] = w5;
+            rr[(rg * 16 + cj) * 8 + 6] = w6;
+            rr[(rg * 16 + cj) * 8 + 7] = jp;
+            __syncthreads();
+            if (tid < 16) {                                          // one thread per instance decides
+                int j = tid;
+                asm volatile("" : "+v"(j));              // opaque: none of this block's addresses are hoisted out of the solve loop
+                const float tolT = inst[16 + 0], thr_p = inst[16 + 1], thr_d = inst[16 + 2], rmin = inst[16 + 3], rmax = inst[16 + 4];
+                float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, obj = 0.f;
+                for (int w = 0; w < NW; ++w) {
+                    q0 = nanmaxf(q0, red[(w * 16 + j) * 4 + 0]);
+                    q1 = nanmaxf(q1, red[(w * 16 + j) * 4 + 1]);
+                    q2 = nanmaxf(q2, red[(w * 16 + j) * 4 + 2]);
+                }
+                for (int g2 = 0; g2 < 16; ++g2) {
+                    q3 = nanmaxf(q3, rr[(g2 * 16 + j) * 8 + 3]);
+                    q4 = nanmaxf(q4, rr[(g2 * 16 + j) * 8 + 4]);
+                    q5 = nanmaxf(q5, rr[(g2 * 16 + j) * 8 + 5]);
+                    q6 = nanmaxf(q6, rr[(g2 * 16 + j) * 8 + 6]);
+                    obj += rr[(g2 * 16 + j) * 8 + 7];
+                }
+                int newly = 0;
+                if (inst_i[5 * 16 + j] == 0) {
+                    const float num = q0 / nanmaxf(q1, q2);                               // :315
+                    const float den = q3 / nanmaxf(nanmaxf(q4, q5), q6);                  // :316
+                    float est = inst[0 * 16 + j] * sqrtf(num / den);                      // :317 (Q4: carried)
+                    if (est < rmin) est = rmin;                                           // torch.clamp: NaN stays NaN
+                    if (est > rmax) est = rmax;
+                    int ri = inst_i[4 * 16 + j];
+                    const int ri_before = ri;
+                    if (!final_chk) {
+                        if (est > rhosf[ri] * tolT && ri < a.nrho - 1) ri += 1;           // :223
+                        else if (est < rhosf[ri] / tolT && ri > 0) ri -= 1;               // :226
+                    }
+                    inst[0 * 16 + j] = est;
+                    inst_i[4 * 16 + j] = ri;
+                    const int chk_no = k / a.check_interval;
+                    if (!final_chk && a.info.trace && chk_no <= a.info.trace_cap) {
+                        double* tr = a.info.trace + ((size_t)(b0 + j) * a.info.trace_cap + (chk_no - 1)) * 4;
+                        tr[0] = (double)q0; tr[1] = (double)q3; tr[2] = (double)est; tr[3] = (double)ri_before;
+                    }
+                    const bool conv = !final_chk && (q0 < thr_p && q3 < thr_d);           // :233
+                    const bool last = final_chk || k >= kmax;                              // :243 max-iter fallthrough
+                    if (conv || last) {
+                        float est_out = est;
+                        if (!conv && !final_chk) {       // max_iter is a multiple of check_interval: the reference runs
+                            // compute_residuals once more on the same state (:243), compounding the estimate again
+                            est_out = est * sqrtf(num / den);
+                            if (est_out < rmin) est_out = rmin;
+                            if (est_out > rmax) est_out = rmax;
+                        }
+                        newly = 1;
+                        inst_i[5 * 16 + j] = 1;
+                        const size_t bj = (size_t)(b0 + j);
+                        if (a.info.iter) a.info.iter[bj] = conv ? k : a.max_iter;
+                        if (a.info.status) a.info.status[bj] = conv ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+                        if (a.info.rho_ind) a.info.rho_ind[bj] = ri;
+                        if (a.info.pri_res) a.info.pri_res[bj] = (double)q0;
+                        if (a.info.dua_res) a.info.dua_res[bj] = (double)q3;
+                        if (a.info.rho_estimate) a.info.rho_estimate[bj] = (double)est_out;
+                        if (a.info.obj_val) a.info.obj_val[bj] = (double)obj;
+                        a.rho_ind[bj] = a.warm_starting ? ri : a.rho_ind0;
+                    }
+                }
+                inst_i[7 * 16 + j] = newly;
+            }
+            __syncthreads();
+            // instances that just finished: x, z, lam out (update_results :278-305) and the persistent state
+            // (sizes and offsets pass through opaque copies so that none of this rare path's predicates and addresses
+            //  are hoisted out of the solve loop as live registers)
+            int n_o = n, m_o = m, tid_o = tid;
+            asm volatile("" : "+s"(n_o), "+s"(m_o), "+v"(tid_o));
+            const int cj_o = tid_o & 15, rg_o = tid_o >> 4, i16_o = tid_o & 15, kq_o = (tid_o >> 4) & 3, wave_o = tid_o >> 6;
+            if (inst_i[7 * 16 + cj_o] && (b0 + cj_o) < a.B) {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) {
+                    const int row = rg_o + 16 * e;
+                    if (row < n_o) {
+                        const size_t o = (size_t)(b0 + cj_o) * n_o + row;
+                        if (a.out_x) ((float*)a.out_x)[o] = xr[e];
+                        a.x[o] = a.warm_starting ? (double)xr[e] : 0.0;
+                    }
+                }
+            }
+            if (inst_i[7 * 16 + i16_o] && (b0 + i16_o) < a.B) {
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * (MBW * wave_o + tl) + 4 * kq_o + r;
+                        if (row < m_o) {
+                            const size_t o = (size_t)(b0 + i16_o) * m_o + row;
+                            if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
+                            if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
+                            a.z[o] = a.warm_starting ? (double)zz[tl][r] : 0.0;
+                            a.lam[o] = a.warm_starting ? (double)lm[tl][r] : 0.0;
+                        }
+                    }
+            }
+            ri_l = inst_i[4 * 16 + i16];
+            set_rho();
+            int nd = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) nd += inst_i[5 * 16 + j];
+            if (nd == 16) break;                         // every instance of the tile has exited
+            stamp(-1);
+#pragma unroll
+            for (int e = 0; e < NB; ++e) V1[(MP + rg + 16 * e) * 16 + cj] = xr[e];    // x rows are already there; keep explicit
+            make_nu();
+            ph = 1;
+        }
+        if (ph == 1) stamp(10); else stamp(-1);
+    }
+    if constexpr (DIAG) {
+        if (lane == 0)
+            for (int e = 0; e < 12; ++e) dbg[((size_t)blockIdx.x * 4 + wave) * 12 + e] = t_acc[e];
+    }
+}
+
+// ---------------------------------------------------------------------------- packing
+// Lane-linear operand images (lane l of an MFMA A-operand holds element [l & 15][l >> 4] of its 16 x 4 tile):
+//   W1[w][s][t][l] = S[4 (KS1 w + s) + (l >> 4)][16 t + (l & 15)],  S = [A (MP rows, zero padded); H' (NP rows)]
+//   W3[w][tl][s][l] = A[16 (MBW w + tl) + (l & 15)][4 s + (l >> 4)]
+//   K[j][w][s][t][l] = K_j[16 t + (l & 15)][4 (KS2 w + s) + (l >> 4)]
+template <class C>
+__global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
+                            const float* __restrict__ K, float* __restrict__ img) {
+    constexpr int NB = C::NB, MBW = C::MBW, MP = C::MP, KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3;
+    const size_t total = C::W1_ELEMS + C::W3_ELEMS + (size_t)nrho * C::KJ_ELEMS;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(idx & 63), i16 = l & 15, kq = l >> 4;
+        float v = 0.f;
+        if (idx < C::W1_ELEMS) {
+            const int q = (int)(idx >> 6), t = q % NB, s = (q / NB) % KS1, w = q / (NB * KS1);
+            const int k = 4 * (KS1 * w + s) + kq, i = 16 * t + i16;
+            if (i < n) {
+                if (k < MP) { if (k < m) v = A[(size_t)k * ldn + i]; }
+                else if (k - MP < n) v = Ht[(size_t)(k - MP) * ldn + i];
+            }
+        } else if (idx < C::W1_ELEMS + C::W3_ELEMS) {
+            const int q = (int)((idx - C::W1_ELEMS) >> 6), s = q % KS3, tl = (q / KS3) % MBW, w = q / (KS3 * MBW);
+            const int r = 16 * (MBW * w + tl) + i16, c = 4 * s + kq;
+            if (r < m && c < n) v = A[(size_t)r * ldn + c];
+        } else {
+            const size_t o = idx - C::W1_ELEMS - C::W3_ELEMS;
+            const int j = (int)(o / C::KJ_ELEMS), q = (int)((o % C::KJ_ELEMS) >> 6), t = q % NB, s = (q / NB) % KS2, w = q / (NB * KS2);
+            const int r = 16 * t + i16, c = 4 * (KS2 * w + s) + kq;
+            if (r < n && c < n) v = K[((size_t)j * n + r) * ldn + c];
+        }
+        img[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+typedef MfmaCfg<5, 5> CfgM55;        // n <= 80, m <= 320   (linear MPC, N=20, nx=12, nu=4 condensed)
+
+bool rqp_mfma_fits(const rqp_handle* h) {
+    return h->esz == 4 && h->dims.shared_mats && h->n <= CfgM55::NP && h->m <= CfgM55::MP && h->nrho <= 64;
+}
+
+size_t rqp_mfma_img_elems(const rqp_handle* h) { return CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS; }
+
+hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
+    k_pack_mfma<CfgM55><<<256, 256, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht, (const float*)h->K, h->W1img);
+    return hipGetLastError();
+}
+hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = CfgM55::lds_floats() * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int tiles = (h->B + 15) / 16;
+    if (const char* dg = getenv("RQP_DIAG")) {
+        if (dg[0] == '1') {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+            unsigned long long* dbg = nullptr;
+            const size_t cnt = (size_t)tiles * 4 * 12;
+            if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k_admm_mfma<CfgM55, true><<<tiles, CfgM55::NT, lds, s>>>(a, h->W1img, dbg);
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> hb(cnt);
+            (void)hipMemcpy(hb.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(dbg);
+            static const char* names[11] = {"top wait", "GEMM1", "wait", "d", "wait", "GEMM2", "wait", "x", "wait", "GEMM3+rows", "next"};
+            for (int w = 0; w < 4; ++w) {
+                double tot[12] = {0};
+                for (int t = 0; t < tiles; ++t)
+                    for (int e = 0; e < 12; ++e) tot[e] += (double)hb[((size_t)t * 4 + w) * 12 + e];
+                fprintf(stderr, "[rqp diag mfma] wave %d, %.1f iterations/tile, s_memtime ticks per iteration:", w, tot[11] / tiles);
+                for (int e = 0; e < 11; ++e) fprintf(stderr, "  %s %.1f", names[e], tot[e] / tot[11]);
+                fprintf(stderr, "\n");
+            }
+            return hipGetLastError();
+        }
+    }
+    k_admm_mfma<CfgM55, false><<<tiles, CfgM55::NT, lds, s>>>(a, h->W1img, nullptr);
+    return hipGetLastError();
+}

@@ -51,3 +51,46 @@ def test_mpc_closed_loop_update_and_warm_start():
                           device=torch.device("cuda:0"), precision=torch.float64, eps_abs=1e-3)
     xs64, us64, _ = ctl64.simulate(x0, steps=40)
     assert np.abs(xs64 - xs).max() < 5e-2 * np.abs(xs).max()
+
+
+@pytest.mark.parametrize("B", [16, 40])
+def test_mfma_kernel_matches_resident_and_oracle(B):
+    """Shared-(H,A) batches on the MFMA kernel (forced with RQP_MFMA=1): same exits as the per-instance resident
+    kernel and the oracle, x within float32 tolerance; ragged last tile (B=40 = 2.5 tiles)."""
+    import os
+    import reluqp.reluqpth as reluqpth
+    ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=11, B=B)
+    g, l, u = ctl.qp_vectors(x0)
+    dev = torch.device("cuda:0")
+    os.environ["RQP_MFMA"] = "1"
+    try:
+        mm = reluqpth.ReLU_QP()
+        mm.collect_trace = True
+        mm.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3)
+    finally:
+        os.environ["RQP_MFMA"] = "0"
+    try:
+        mr = reluqpth.ReLU_QP()
+        mr.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3)
+    finally:
+        del os.environ["RQP_MFMA"]
+    assert mm.kernel == "mfma" and mr.kernel.startswith("resident")
+    rm, rr = mm.solve(), mr.solve()
+    ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", eps_abs=1e-3)
+    itm, itr = rm.info.iter.cpu().numpy(), rr.info.iter.cpu().numpy()
+    assert rm.info.status == ref["status"]
+    assert np.mean(itm == ref["iter"]) >= 0.85 and np.mean(itm == itr) >= 0.85
+    same = itm == ref["iter"]
+    scale = max(1.0, np.abs(ref["x"]).max())
+    np.testing.assert_allclose(rm.x.cpu().double().numpy()[same], ref["x"][same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.z.cpu().double().numpy()[same], ref["z"][same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.y.cpu().double().numpy()[same], ref["lam"][same], rtol=0, atol=2e-3 * max(1.0, np.abs(ref["lam"]).max()))
+    np.testing.assert_allclose(rm.info.obj_val.cpu().double().numpy()[same], ref["obj_val"][same], rtol=1e-3, atol=1e-3)
+    assert np.array_equal(rm.info.rho_ind.cpu().numpy()[same], ref["rho_ind"][same])
+    # warm re-solve after update() goes through the same kernel and persists its state
+    g2, l2, u2 = ctl.qp_vectors(0.9 * x0)
+    mm.update(g=g2, l=l2, u=u2)
+    r2 = mm.solve()
+    ref2 = O.solve_batch(ctl.H, g2, ctl.A, l2, u2, form="factored", eps_abs=1e-3)
+    assert all(s == "solved" for s in r2.info.status)
+    assert r2.info.iter.double().mean() <= ref2["iter"].mean()          # warm start: no slower than cold
