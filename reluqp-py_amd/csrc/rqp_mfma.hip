@@ -39,7 +39,7 @@ struct MfmaCfg {
     static constexpr size_t W1_ELEMS = (size_t)NW * KS1 * NB * 64, W3_ELEMS = (size_t)NW * MBW * KS3 * 64;
     static constexpr size_t KJ_ELEMS = (size_t)NW * KS2 * NB * 64;
     static constexpr size_t lds_floats() {
-        return (size_t)KT * 16 + 2 * NP * 16 + NW * NP * 16 + 3 * MP * 16 + NB * NT + NP * 16 + NW * 16 * 4 + 16 * 16 * 8 + 64 + 8 * 16;
+        return (size_t)KT * 16 + NP * 16 + 2 * NW * NP * 16 + 3 * MP * 16 + NB * NT + NP * 16 + NW * 16 * 4 + 16 * 16 * 8 + 64 + 8 * 16;
     }
 };
 
@@ -48,16 +48,23 @@ __device__ __forceinline__ float nanmaxf(float a, float b) {          // NaN-pro
 }
 
 // DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles each wave spends per segment.
+// Swizzle of the [row][16] LDS arrays that are written in the MFMA D layout (lane = column, rows 16 T + 4 kq + r) and read
+// in the MFMA B layout (lane kq reads row 4 S + kq) -- V1, part, part2: each group of 4 rows (64 floats = one pass over
+// the banks) is rotated by 16 * (group & 3):
+//      addr(row, col) = (row >> 2) * 64 + ((16 * (row & 3) + col + 16 * ((row >> 2) & 3)) & 63)
+// which makes BOTH access patterns conflict-free (unrotated, the four kq of a D-layout write hit the same bank).
+// The kernel forms these addresses as base + compile-time offset (dl_base / bl_base / co_base below).
+
 template <class C, bool DIAG>
 __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* __restrict__ img, unsigned long long* __restrict__ dbg) {
     constexpr int NB = C::NB, MBW = C::MBW, NT = C::NT, NW = C::NW, NP = C::NP, MP = C::MP, KT = C::KT;
     constexpr int KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* V1 = sm;                          // [KT][16]  rows 0..MP-1: nu (lam / 0 at a check); rows MP..: x (0 at a check)
-    float* V2 = V1 + KT * 16;                // [NP][16]  d
-    float* V3 = V2 + NP * 16;                // [NP][16]  dx
-    float* part = V3 + NP * 16;              // [NW][NP][16] wave partials (GEMM1 / GEMM2)
-    float* LB = part + NW * NP * 16;         // [4 MBW][NT] l of the lane's own rows (lane-linear: conflict-free, owner-only)
+    float* V1 = sm;                          // [KT][16] (swizzled rows)  rows 0..MP-1: nu (lam / 0 at a check); rows MP..: x (0 at a check)
+    float* V3 = V1 + KT * 16;                // [NP][16]  dx (x at the start)
+    float* part = V3 + NP * 16;              // [NW][NP][16] wave partials of GEMM1 (swizzled rows)
+    float* part2 = part + NW * NP * 16;      // [NW][NP][16] wave partials of GEMM2
+    float* LB = part2 + NW * NP * 16;        // [4 MBW][NT] l of the lane's own rows (lane-linear: conflict-free, owner-only)
     float* UB = LB + MP * 16;                // [4 MBW][NT] u
     float* ZL = UB + MP * 16;                // [4 MBW][NT] low word of the float-float A x
     float* T3 = ZL + MP * 16;                // [NB][NT]    A' lam of the pending check
@@ -79,6 +86,19 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 
     // ---- resident A-operands (images: see MfmaCfg) -------------------------------------------------------------------
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Swizzled addresses as (per-phase base) + (compile-time offset).  The bases are recomputed from an opaque copy of
+    // the lane id at the top of each phase (OPQ): a handful of VALU ops, instead of dozens of loop-invariant address
+    // registers that LICM would otherwise keep alive across the whole solve loop.
+#define OPQ(v) asm volatile("" : "+v"(v))
+    // D-layout element (row 16 T + 4 kq + r, column i16) -> base(r) + 256 T      [T counted inside the array]
+    auto dl_base = [&](int lp, int r) __attribute__((always_inline)) { return (lp >> 4) * 64 + ((lp + 16 * r) & 63); };
+    // B-layout element (row 4 (S0 + s) + kq, column i16) -> base(s & 3) + 64 s   [S0 = first k-step of this wave]
+    auto bl_base = [&](int lp, int S0, int c) __attribute__((always_inline)) { return S0 * 64 + ((lp + 16 * ((S0 + c) & 3)) & 63); };
+    // column-owner element (row rg + 16 e, column cj), tp = thread id -> base + 256 e
+    auto co_base = [&](int tp) __attribute__((always_inline)) {
+        const int cjp = tp & 15, rgp = tp >> 4;
+        return (rgp >> 2) * 64 + ((16 * (rgp & 3) + cjp + 16 * ((rgp >> 2) & 3)) & 63);
+    };
     float aw1[KS1][NB];              // GEMM1: S[4 (KS1 wave + s) + kq][16 t + i16],  S = [A (MP rows); H' (NP rows)]
     {
         const float* w1 = img + (size_t)wave_u * KS1 * NB * 64 + lane;
@@ -140,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         const bool ok = cinst_ok && row < n;
         xr[e] = ok ? (float)a.x[bc * n + row] : 0.f;
         GV[row * 16 + cj] = ok ? ((const float*)a.g)[bc * n + row] : 0.f;
-        V1[(MP + row) * 16 + cj] = xr[e];
+        V1[MP * 16 + co_base(tid) + 256 * e] = xr[e];
         V3[row * 16 + cj] = xr[e];                        // A x of the incoming state: GEMM3 on x
     }
     __syncthreads();
@@ -166,6 +186,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 
     // lam_hat and nu of the next iteration from the current state (p = A x - z)
     auto make_nu = [&]() __attribute__((always_inline)) {
+        int lp = lane;
+        OPQ(lp);
+        int nb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nb[r] = 4 * MBW * wave_u * 64 + dl_base(lp, r);
 #pragma unroll
         for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
@@ -174,7 +199,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 const float p = (zh[tl][r] - zz[tl][r]) + ZL[(4 * tl + r) * NT + tid];
                 const float lh = lm[tl][r] + rho * p;
                 lm[tl][r] = lh;
-                V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = lh + rho * p;
+                V1[nb[r] + 256 * tl] = lh + rho * p;
             }
     };
 
@@ -207,43 +232,53 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             f32x4 acc[NB];
 #pragma unroll
             for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float bv[KS1];                                           // all B operands first: no LDS latency inside the MFMA stream
+            int lp = lane;
+            OPQ(lp);
+            {
+                int rb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rb[c] = bl_base(lp, KS1 * wave_u, c);
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) bv[s] = V1[rb[s & 3] + 64 * s];
+            }
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
-                const float bv = V1[(4 * (KS1 * wave + s) + kq) * 16 + i16];
 #pragma unroll
                 for (int t = 0; t < NB; ++t) {
                     asm volatile("" ::"a"(aw1[s][t]));              // keep the operand in its AGPR: the MFMA reads it from there
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw1[s][t], bv, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw1[s][t], bv[s], acc[t], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int t = 0; t < NB; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[(wave * NP + 16 * t + 4 * kq + r) * 16 + i16] = acc[t][r];
+                for (int r = 0; r < 4; ++r) part[wave_u * NP * 16 + dl_base(lp, r) + 256 * t] = acc[t][r];
             stamp(1);
             __syncthreads();
             stamp(2);
         }
         bool run_g3 = (ph == 0);
         if (ph == 1) {
-#pragma unroll
-            for (int e = 0; e < NB; ++e) {                            // d = g + sum of the 4 partials (fixed order)
-                const int row = rg + 16 * e;
-                float d = GV[row * 16 + cj];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) d += part[(w * NP + row) * 16 + cj];
-                V2[row * 16 + cj] = d;
-            }
-            stamp(3);
-            __syncthreads();
-            stamp(4);
             {                                                        // dx partial = K_j d, K_j chosen per column
                 f32x4 sel[NB];
 #pragma unroll
                 for (int t = 0; t < NB; ++t) sel[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float bv[KS2];
+                float bv[KS2];                                       // B operands: d = g + sum of the 4 partials (fixed order)
+                int lp = lane;
+                OPQ(lp);
+                {
+                    int gb[4];
 #pragma unroll
-                for (int s = 0; s < KS2; ++s) bv[s] = V2[(4 * (KS2 * wave + s) + kq) * 16 + i16];
+                    for (int c = 0; c < 4; ++c) gb[c] = bl_base(lp, KS2 * wave_u, c);
+#pragma unroll
+                    for (int s = 0; s < KS2; ++s) {
+                        float d = GV[(KS2 * wave_u + s) * 64 + lp];      // g[4 S + kq][i16]
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) d += part[w * NP * 16 + gb[s & 3] + 64 * s];
+                        bv[s] = d;
+                    }
+                }
                 unsigned long long todo = __ballot(lane < 16);       // one representative lane per instance column
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
@@ -293,21 +328,25 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 #pragma unroll
                 for (int t = 0; t < NB; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) part[(wave * NP + 16 * t + 4 * kq + r) * 16 + i16] = sel[t][r];
+                    for (int r = 0; r < 4; ++r) part2[wave_u * NP * 16 + dl_base(lp, r) + 256 * t] = sel[t][r];
             }
             stamp(5);
             __syncthreads();
             stamp(6);
+            {
+                int tp = tid;
+                OPQ(tp);
+                const int xb = co_base(tp);
 #pragma unroll
-            for (int e = 0; e < NB; ++e) {                            // dx = -K d ; x += dx
-                const int row = rg + 16 * e;
-                float kd = 0.f;
+                for (int e = 0; e < NB; ++e) {                        // dx = -K d ; x += dx
+                    float kd = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) kd += part[(w * NP + row) * 16 + cj];
-                const float dx = -kd;
-                xr[e] += dx;
-                V3[row * 16 + cj] = dx;
-                V1[(MP + row) * 16 + cj] = xr[e];
+                    for (int w = 0; w < NW; ++w) kd += part2[w * NP * 16 + xb + 256 * e];
+                    const float dx = -kd;
+                    xr[e] += dx;
+                    V3[tp + 256 * e] = dx;                            // [rg + 16 e][cj]
+                    V1[MP * 16 + xb + 256 * e] = xr[e];
+                }
             }
             stamp(7);
             __syncthreads();
@@ -315,49 +354,78 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             if constexpr (DIAG) t_acc[11] += 1;
             run_g3 = true;
         }
+        bool nu_done = false;
         if (run_g3) {                                    // ---------------- GEMM3: (A V3)[rows of this wave][16]
-            f32x4 acc[MBW];
+            // Row tiles one after the other: the row update of tile tl (VALU + LDS) runs in the shadow of tile tl+1's MFMAs.
+            // start (ph 0): V3 = x, A x accumulates from 0, z and lam stay; otherwise A x += A dx, z = clamp(A x + lam_hat / rho)
+            // and, when no check follows, lam_hat / nu of the next iteration right away (what make_nu does after a check).
+            const bool upd = (ph == 1);
+            const bool fin_next = upd && (k + 1 >= kmax) && (to_chk != 1);
+            const bool with_nu = upd && to_chk != 1 && !fin_next;
+            int lp = lane;
+            OPQ(lp);
+            int nb[4];
 #pragma unroll
-            for (int tl = 0; tl < MBW; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) nb[r] = 4 * MBW * wave_u * 64 + dl_base(lp, r);
+            float bv[KS3];
 #pragma unroll
-            for (int s = 0; s < KS3; ++s) {
-                const float bv = V3[(4 * s + kq) * 16 + i16];
+            for (int s = 0; s < KS3; ++s) bv[s] = V3[64 * s + lp];      // dx[4 s + kq][i16]
+            // One row tile after the other: its LDS operands (A x low word, l, u) are requested first and arrive while the
+            // tile's KS3-long MFMA chain runs.  (fp32 MFMA and VALU do not overlap on this hardware -- tools/mfma_rate.hip --
+            // so the row update itself is simply kept short: uniform branches instead of per-row selects.)
 #pragma unroll
-                for (int tl = 0; tl < MBW; ++tl) {
-                    asm volatile("" ::"a"(a3[tl][s]));          // keep the operand in its AGPR: the MFMA reads it from there
-                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[tl][s], bv, acc[tl], 0, 0, 0);
+            for (int tl = 0; tl < MBW; ++tl) {
+                float pz[4], pl[4], pu[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pz[r] = ZL[(4 * tl + r) * NT + tid];
+                    pl[r] = LB[(4 * tl + r) * NT + tid];
+                    pu[r] = UB[(4 * tl + r) * NT + tid];
                 }
-            }
-            if (ph == 0) {                               // A x of the incoming state
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tl = 0; tl < MBW; ++tl)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zh[tl][r] = acc[tl][r];
-            } else {                                     // A x += A dx ; z = clamp(A x + lam_hat / rho, l, u)
-#pragma unroll
-                for (int tl = 0; tl < MBW; ++tl)
+                for (int s = 0; s < KS3; ++s) {
+                    asm volatile("" ::"a"(a3[tl][s]));          // keep the operand in its AGPR: the MFMA reads it from there
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[tl][s], bv[s], acc, 0, 0, 0);
+                }
+                {                                            // (start: upd false -- A x accumulates from 0, z stays)
+                    float pp[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float adx = acc[tl][r];    // float-float accumulation of A x (two-sum + renormalisation)
+                        const float adx = acc[r];            // float-float accumulation of A x (two-sum + renormalisation)
                         const float sgm = zh[tl][r] + adx;
                         const float bb = sgm - zh[tl][r];
                         const float err = (zh[tl][r] - (sgm - bb)) + (adx - bb);
-                        const float lo = ZL[(4 * tl + r) * NT + tid] + err;
+                        const float lo = pz[r] + err;
                         const float hi = sgm + lo;
                         const float zlo = lo - (hi - sgm);
                         ZL[(4 * tl + r) * NT + tid] = zlo;
                         zh[tl][r] = hi;
-                        const float irho = ((eqmask >> (4 * tl + r)) & 1u) ? inv_eq : inv_ne;
-                        const float v = hi + (zlo + lm[tl][r] * irho);
-                        const float lo_b = LB[(4 * tl + r) * NT + tid], up_b = UB[(4 * tl + r) * NT + tid];
-                        float zn = v;                    // torch.clamp: NaN stays NaN
-                        if (v < lo_b) zn = lo_b;
-                        if (v > up_b) zn = up_b;
+                        const bool eq = (eqmask >> (4 * tl + r)) & 1u;
+                        const float v = hi + (zlo + lm[tl][r] * (eq ? inv_eq : inv_ne));
+                        float zn = v;                        // torch.clamp: NaN stays NaN
+                        if (v < pl[r]) zn = pl[r];
+                        if (v > pu[r]) zn = pu[r];
+                        zn = upd ? zn : zz[tl][r];
                         zz[tl][r] = zn;
+                        pp[r] = (hi - zn) + zlo;             // p = A x - z of the new state
                     }
+                    if (with_nu) {                           // lam_hat, nu of the next iteration
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float rho = ((eqmask >> (4 * tl + r)) & 1u) ? rho_eq : rho_ne;
+                            const float lh = lm[tl][r] + rho * pp[r];
+                            lm[tl][r] = lh;
+                            V1[nb[r] + 256 * tl] = lh + rho * pp[r];
+                        }
+                    }
+                }
+            }
+            if (upd) {
                 k += 1;
                 to_chk -= 1;
             }
+            nu_done = with_nu;
             stamp(9);
         }
         // ---------------------------------------------------------------------------------- what comes next
@@ -366,10 +434,14 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             const bool chk = (ph == 1 && to_chk == 0) || final_chk;                       // :218 (Q3 fixed) / :243
             if (to_chk == 0) to_chk = a.check_interval;
             if (!chk) {
-                make_nu();
+                if (!nu_done) make_nu();                 // (only after the start pass; iterations fold it into the row update)
                 ph = 1;
             } else {                                     // check part 1: V1 = [lam; 0], row-side maxima
                 v0 = 0.f; v1 = 0.f; v2 = 0.f;
+                int lp = lane, tp = tid;
+                OPQ(lp);
+                OPQ(tp);
+                const int xb = co_base(tp);
 #pragma unroll
                 for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
@@ -378,26 +450,29 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         v0 = nanmaxf(v0, fabsf((zh[tl][r] - zz[tl][r]) + zlo));
                         v1 = nanmaxf(v1, fabsf(zh[tl][r] + zlo));
                         v2 = nanmaxf(v2, fabsf(zz[tl][r]));
-                        V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = lm[tl][r];
+                        V1[4 * MBW * wave_u * 64 + dl_base(lp, r) + 256 * tl] = lm[tl][r];
                     }
 #pragma unroll
-                for (int e = 0; e < NB; ++e) V1[(MP + rg + 16 * e) * 16 + cj] = 0.f;
+                for (int e = 0; e < NB; ++e) V1[MP * 16 + xb + 256 * e] = 0.f;
                 ph = 2;
             }
         } else if (ph == 2) {                            // t3 = A' lam ; then V1 = [0; x]
+            int lp = lane, tp = tid;
+            OPQ(lp);
+            OPQ(tp);
+            const int xb = co_base(tp);
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
-                const int row = rg + 16 * e;
                 float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) t += part[(w * NP + row) * 16 + cj];
+                for (int w = 0; w < NW; ++w) t += part[w * NP * 16 + xb + 256 * e];
                 T3[e * NT + tid] = t;
-                V1[(MP + row) * 16 + cj] = xr[e];
+                V1[MP * 16 + xb + 256 * e] = xr[e];
             }
 #pragma unroll
             for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) V1[(16 * (MBW * wave + tl) + 4 * kq + r) * 16 + i16] = 0.f;
+                for (int r = 0; r < 4; ++r) V1[4 * MBW * wave_u * 64 + dl_base(lp, r) + 256 * tl] = 0.f;
             ph = 3;
         } else {                                         // ph == 3: t2 = H x ; residuals and decisions
             v0 = nanmaxf(v0, __shfl_xor(v0, 16, 64)); v0 = nanmaxf(v0, __shfl_xor(v0, 32, 64));
@@ -409,12 +484,15 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 red[(wave * 16 + i16) * 4 + 2] = v2;
             }
             float w3 = 0.f, w4 = 0.f, w5 = 0.f, w6 = 0.f, jp = 0.f;
+            int tp3 = tid;
+            OPQ(tp3);
+            const int xb3 = co_base(tp3);
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
                 const int row = rg + 16 * e;
                 float t2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) t2 += part[(w * NP + row) * 16 + cj];
+                for (int w = 0; w < NW; ++w) t2 += part[w * NP * 16 + xb3 + 256 * e];
                 const float ge = GV[row * 16 + cj], t3 = T3[e * NT + tid];
                 w3 = nanmaxf(w3, fabsf(t2 + t3 + ge));
                 w4 = nanmaxf(w4, fabsf(t2));
@@ -531,7 +609,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             if (nd == 16) break;                         // every instance of the tile has exited
             stamp(-1);
 #pragma unroll
-            for (int e = 0; e < NB; ++e) V1[(MP + rg + 16 * e) * 16 + cj] = xr[e];    // x rows are already there; keep explicit
+            for (int e = 0; e < NB; ++e) V1[MP * 16 + xb3 + 256 * e] = xr[e];    // x rows are already there; keep explicit
             make_nu();
             ph = 1;
         }
