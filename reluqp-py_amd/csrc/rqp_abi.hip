@@ -67,7 +67,7 @@ int argmin_abs(const std::vector<double>& r, double v) {   // np.argmin(np.abs(r
 void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
-                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img};
+                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img, (void**)&h->queue};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -228,6 +228,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
                   (h->B >= 1024 || (mf && mf[0] == '1'));
     if (h->use_mfma) {
         HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));
         HIP_TRY(h, rqp_launch_pack_mfma(h, s));
         h->kernel_name = "mfma";
     }

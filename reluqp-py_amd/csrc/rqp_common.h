@@ -47,7 +47,8 @@ struct rqp_handle {
     bool resident = false;
     int res_kind = 0;             // 1: rqp_resident.hip (row-block layout), 2: rqp_resident2.hip (column block per wave)
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
-    float* W1img = nullptr;       // lane-linear GEMM1 operand image ([A; H'] as MFMA A-operands)
+    float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
+    int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
 
     const char* kernel_name = "generic";
     std::string err;

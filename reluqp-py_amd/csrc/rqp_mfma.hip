@@ -56,7 +56,7 @@ __device__ __forceinline__ float nanmaxf(float a, float b) {          // NaN-pro
 // The kernel forms these addresses as base + compile-time offset (dl_base / bl_base / co_base below).
 
 template <class C, bool DIAG>
-__global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* __restrict__ img, unsigned long long* __restrict__ dbg) {
+__global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* __restrict__ img, int* __restrict__ queue, unsigned long long* __restrict__ dbg) {
     constexpr int NB = C::NB, MBW = C::MBW, NT = C::NT, NW = C::NW, NP = C::NP, MP = C::MP, KT = C::KT;
     constexpr int KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -72,17 +72,19 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     float* red = GV + NP * 16;               // [NW][16][4] row-side maxima per (wave, instance)
     float* rr = red + NW * 16 * 4;           // [16 rowgroups][16][8] column-side maxima per (row group, instance)
     float* rhosf = rr + 16 * 16 * 8;         // [64] rho ladder
-    float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 1 settings, 4 ri (int), 5 done (int), 7 newly (int)
+    float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 1 settings, 2 instance id, 3 k at its start, 4 rho index,
+                                             //          5 done, 6 column to (re)load, 7 id + 1 of an instance that just exited
     int* inst_i = (int*)inst;
 
     const int n = a.n, m = a.m, ldn = a.ldn;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;       // MFMA lane coordinates
     const int cj = tid & 15, rg = tid >> 4;          // column-owner coordinates: instance cj, rows rg + 16 e
-    const int b0 = blockIdx.x * 16;                  // first instance of the tile
-    const bool inst_ok = (b0 + i16) < a.B;           // this lane's MFMA column is a real instance
-    const bool cinst_ok = (b0 + cj) < a.B;
-    const size_t bi = (size_t)(b0 + i16), bc = (size_t)(b0 + cj);
+    // Columns are SLOTS: slot c of workgroup b starts with instance 16 b + c; with a queue (persistent grid, large batches)
+    // a slot whose instance has exited takes the next unsolved instance at the same check, so no MFMA column idles while
+    // there is work left and the tile does not wait for its slowest member.
+    const int kmax = a.max_iter;
+    const bool refill = queue != nullptr && kmax > 0 && (kmax % a.check_interval) == 0;
 
     // ---- resident A-operands (images: see MfmaCfg) -------------------------------------------------------------------
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -129,53 +131,17 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     // ---- per-instance scalars and vectors -----------------------------------------------------------------------
     for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
     if (tid < 16) {
-        const bool ok = (b0 + tid) < a.B;
-        inst_i[4 * 16 + tid] = a.rho_ind[ok ? b0 + tid : b0];      // padding columns mirror instance b0 (no extra K block)
+        const int id = blockIdx.x * 16 + tid;
+        const bool ok = id < a.B;
+        const int ri = a.rho_ind[ok ? id : blockIdx.x * 16];       // padding columns mirror the tile's first instance (no extra K block)
+        inst_i[2 * 16 + tid] = id;
+        inst_i[3 * 16 + tid] = 0;
+        inst_i[4 * 16 + tid] = ri;
         inst_i[5 * 16 + tid] = ok ? 0 : 1;                         // padding columns start "done"
+        inst_i[6 * 16 + tid] = 1;                                  // every column loads its instance
         inst_i[7 * 16 + tid] = 0;
+        inst[0 * 16 + tid] = (float)a.rhos[ri];                    // rho_est = rhos[rho_ind]  (:211)
     }
-    // row state (wave w owns rows [16 MBW w, 16 MBW (w+1)); lane: instance i16, rows 16 T + 4 kq + r)
-    float zh[MBW][4], zz[MBW][4], lm[MBW][4];           // (the low word of A x lives in ZL)
-    unsigned eqmask = 0;                                  // bit (4 tl + r): equality row (rho * 1e3)
-#pragma unroll
-    for (int tl = 0; tl < MBW; ++tl)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * (MBW * wave + tl) + 4 * kq + r;
-            const bool ok = inst_ok && row < m;
-            zh[tl][r] = 0.f;
-            ZL[(4 * tl + r) * NT + tid] = 0.f;
-            zz[tl][r] = ok ? (float)a.z[bi * m + row] : 0.f;
-            lm[tl][r] = ok ? (float)a.lam[bi * m + row] : 0.f;
-            LB[(4 * tl + r) * NT + tid] = ok ? ((const float*)a.l)[bi * m + row] : 0.f;
-            UB[(4 * tl + r) * NT + tid] = ok ? ((const float*)a.u)[bi * m + row] : 0.f;
-            const float cv = (row < m) ? ((const float*)a.c)[(inst_ok ? bi : 0) * m + row] : 1.f;
-            if (cv > 1.f) eqmask |= 1u << (4 * tl + r);
-        }
-    // column state: x of rows rg + 16 e of instance cj (g in LDS)
-    float xr[NB];
-#pragma unroll
-    for (int e = 0; e < NB; ++e) {
-        const int row = rg + 16 * e;
-        const bool ok = cinst_ok && row < n;
-        xr[e] = ok ? (float)a.x[bc * n + row] : 0.f;
-        GV[row * 16 + cj] = ok ? ((const float*)a.g)[bc * n + row] : 0.f;
-        V1[MP * 16 + co_base(tid) + 256 * e] = xr[e];
-        V3[row * 16 + cj] = xr[e];                        // A x of the incoming state: GEMM3 on x
-    }
-    __syncthreads();
-    if (tid < 16) inst[0 * 16 + tid] = rhosf[inst_i[4 * 16 + tid]];               // rho_est = rhos[rho_ind]  (:211)
-    int ri_l = inst_i[4 * 16 + i16];                      // rho index of this lane's MFMA column
-    float rho_ne, rho_eq, inv_ne, inv_eq;                 // rho of this lane's instance (plain / equality rows) and inverses
-    auto set_rho = [&]() __attribute__((always_inline)) {
-        rho_ne = rhosf[ri_l];
-        rho_eq = rho_ne * 1e3f;
-        inv_ne = 1.0f / rho_ne;
-        inv_eq = 1.0f / rho_eq;
-    };
-    set_rho();
-
-    const int kmax = a.max_iter;
     if (tid == 0) {                                       // float copies of the scalar settings, read back in the decision block
         inst[16 + 0] = (float)a.tol;
         inst[16 + 1] = (float)a.thr_p;
@@ -183,6 +149,24 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         inst[16 + 3] = (float)a.rho_min;
         inst[16 + 4] = (float)a.rho_max;
     }
+    // row state (wave w owns rows [16 MBW w, 16 MBW (w+1)); lane: slot i16, rows 16 T + 4 kq + r); the low word of A x lives in ZL
+    float zh[MBW][4], zz[MBW][4], lm[MBW][4];
+    unsigned eqmask = 0;                                  // bit (4 tl + r): equality row (rho * 1e3)
+    float xr[NB];                                         // column state: x of rows rg + 16 e of slot cj (g in LDS)
+#pragma unroll
+    for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zh[tl][r] = zz[tl][r] = lm[tl][r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) xr[e] = 0.f;
+    int ri_l = 0;                                         // rho index of this lane's MFMA column
+    float rho_ne = 1.f, rho_eq = 1.f, inv_ne = 1.f, inv_eq = 1.f;   // rho of this lane's instance (plain / equality rows), inverses
+    auto set_rho = [&]() __attribute__((always_inline)) {
+        rho_ne = rhosf[ri_l];
+        rho_eq = rho_ne * 1e3f;
+        inv_ne = 1.0f / rho_ne;
+        inv_eq = 1.0f / rho_eq;
+    };
 
     // lam_hat and nu of the next iteration from the current state (p = A x - z)
     auto make_nu = [&]() __attribute__((always_inline)) {
@@ -204,11 +188,12 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     };
 
     // The loop is a small state machine so that each GEMM has ONE call site (one copy of its operands' live ranges):
-    //   ph 0  start: GEMM3 on x -> A x of the incoming state
+    //   ph 4  load the state of the flagged slots (all of them at the start; refilled ones later)
+    //   ph 0  start: GEMM3 on x of the loaded slots (0 elsewhere) -> A x of the incoming state
     //   ph 1  iterate: GEMM1 -> d -> GEMM2 -> dx, x -> GEMM3 -> row update
     //   ph 2  check, part 1: GEMM1 on [lam; 0] -> t3 = A' lam
     //   ph 3  check, part 2: GEMM1 on [0; x]   -> t2 = H x ; residuals, rho moves, exits (compute_residuals :307-318)
-    int ph = 0, k = 0, to_chk = a.check_interval;         // to_chk: iterations until k is a multiple of check_interval
+    int ph = 4, k = 0, to_chk = a.check_interval;         // to_chk: iterations until k is a multiple of check_interval
     bool final_chk = false;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;                  // row-side maxima of the pending check
 
@@ -227,6 +212,54 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 
     while (true) {
         __syncthreads();
+        if (ph == 4) {
+            // (sizes and ids pass through opaque copies so that none of this rare path's predicates and addresses are hoisted
+            //  out of the solve loop as live registers)
+            int n_o = n, m_o = m, tp = tid;
+            asm volatile("" : "+s"(n_o), "+s"(m_o), "+v"(tp));
+            const int c_o = tp & 15, rg_o = tp >> 4, kq_o = (tp >> 4) & 3, wave_o = tp >> 6;
+            const int id = inst_i[2 * 16 + c_o];
+            const bool fresh = inst_i[6 * 16 + c_o] != 0, real = id < a.B;
+            if (fresh) {
+                unsigned em = 0;
+#pragma unroll
+                for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * (MBW * wave_o + tl) + 4 * kq_o + r;
+                        const bool ok = real && row < m_o;
+                        const size_t o = (size_t)(real ? id : 0) * m_o + (row < m_o ? row : 0);
+                        zh[tl][r] = 0.f;
+                        ZL[(4 * tl + r) * NT + tp] = 0.f;
+                        zz[tl][r] = ok ? (float)a.z[o] : 0.f;
+                        lm[tl][r] = ok ? (float)a.lam[o] : 0.f;
+                        LB[(4 * tl + r) * NT + tp] = ok ? ((const float*)a.l)[o] : 0.f;
+                        UB[(4 * tl + r) * NT + tp] = ok ? ((const float*)a.u)[o] : 0.f;
+                        const float cv = (row < m_o) ? ((const float*)a.c)[o] : 1.f;
+                        if (cv > 1.f) em |= 1u << (4 * tl + r);
+                    }
+                eqmask = em;
+            }
+            const int xb = co_base(tp);
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int row = rg_o + 16 * e;
+                if (fresh) {
+                    const bool ok = real && row < n_o;
+                    const size_t o = (size_t)(real ? id : 0) * n_o + (row < n_o ? row : 0);
+                    xr[e] = ok ? (float)a.x[o] : 0.f;
+                    GV[tp + 256 * e] = ok ? ((const float*)a.g)[o] : 0.f;      // [rg + 16 e][cj]
+                }
+                V3[tp + 256 * e] = fresh ? xr[e] : 0.f;          // GEMM3 on x: A x of the loaded slots, + 0 for the others
+                V1[MP * 16 + xb + 256 * e] = xr[e];
+            }
+            __syncthreads();
+            if (tid < 16) inst_i[6 * 16 + tid] = 0;
+            ri_l = inst_i[4 * 16 + i16];
+            set_rho();
+            ph = 0;
+            __syncthreads();
+        }
         stamp(0);
         if (ph != 0) {                                   // ---------------- GEMM1: wave partial of S' V1
             f32x4 acc[NB];
@@ -360,7 +393,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             // start (ph 0): V3 = x, A x accumulates from 0, z and lam stay; otherwise A x += A dx, z = clamp(A x + lam_hat / rho)
             // and, when no check follows, lam_hat / nu of the next iteration right away (what make_nu does after a check).
             const bool upd = (ph == 1);
-            const bool fin_next = upd && (k + 1 >= kmax) && (to_chk != 1);
+            const bool fin_next = upd && !refill && (k + 1 >= kmax) && (to_chk != 1);
             const bool with_nu = upd && to_chk != 1 && !fin_next;
             int lp = lane;
             OPQ(lp);
@@ -430,7 +463,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         }
         // ---------------------------------------------------------------------------------- what comes next
         if (ph == 0 || ph == 1) {
-            final_chk = (ph == 0) ? (kmax == 0) : (k >= kmax && to_chk != 0);
+            final_chk = !refill && ((ph == 0) ? (kmax == 0) : (k >= kmax && to_chk != 0));
             const bool chk = (ph == 1 && to_chk == 0) || final_chk;                       // :218 (Q3 fixed) / :243
             if (to_chk == 0) to_chk = a.check_interval;
             if (!chk) {
@@ -538,13 +571,14 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     }
                     inst[0 * 16 + j] = est;
                     inst_i[4 * 16 + j] = ri;
-                    const int chk_no = k / a.check_interval;
+                    const int id = inst_i[2 * 16 + j], kc = k - inst_i[3 * 16 + j];       // this instance's own iteration count
+                    const int chk_no = kc / a.check_interval;
                     if (!final_chk && a.info.trace && chk_no <= a.info.trace_cap) {
-                        double* tr = a.info.trace + ((size_t)(b0 + j) * a.info.trace_cap + (chk_no - 1)) * 4;
+                        double* tr = a.info.trace + ((size_t)id * a.info.trace_cap + (chk_no - 1)) * 4;
                         tr[0] = (double)q0; tr[1] = (double)q3; tr[2] = (double)est; tr[3] = (double)ri_before;
                     }
                     const bool conv = !final_chk && (q0 < thr_p && q3 < thr_d);           // :233
-                    const bool last = final_chk || k >= kmax;                              // :243 max-iter fallthrough
+                    const bool last = final_chk || kc >= kmax;                             // :243 max-iter fallthrough
                     if (conv || last) {
                         float est_out = est;
                         if (!conv && !final_chk) {       // max_iter is a multiple of check_interval: the reference runs
@@ -553,10 +587,10 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                             if (est_out < rmin) est_out = rmin;
                             if (est_out > rmax) est_out = rmax;
                         }
-                        newly = 1;
+                        newly = id + 1;
                         inst_i[5 * 16 + j] = 1;
-                        const size_t bj = (size_t)(b0 + j);
-                        if (a.info.iter) a.info.iter[bj] = conv ? k : a.max_iter;
+                        const size_t bj = (size_t)id;
+                        if (a.info.iter) a.info.iter[bj] = conv ? kc : a.max_iter;
                         if (a.info.status) a.info.status[bj] = conv ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
                         if (a.info.rho_ind) a.info.rho_ind[bj] = ri;
                         if (a.info.pri_res) a.info.pri_res[bj] = (double)q0;
@@ -564,6 +598,18 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         if (a.info.rho_estimate) a.info.rho_estimate[bj] = (double)est_out;
                         if (a.info.obj_val) a.info.obj_val[bj] = (double)obj;
                         a.rho_ind[bj] = a.warm_starting ? ri : a.rho_ind0;
+                        if (refill) {                    // this slot takes the next unsolved instance
+                            const int nxt = (int)gridDim.x * 16 + atomicAdd(queue, 1);
+                            if (nxt < a.B) {
+                                const int rn = a.rho_ind[nxt];
+                                inst_i[2 * 16 + j] = nxt;
+                                inst_i[3 * 16 + j] = k;
+                                inst_i[4 * 16 + j] = rn;
+                                inst_i[5 * 16 + j] = 0;
+                                inst_i[6 * 16 + j] = 1;
+                                inst[0 * 16 + j] = rhosf[rn];
+                            }
+                        }
                     }
                 }
                 inst_i[7 * 16 + j] = newly;
@@ -574,26 +620,25 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             //  are hoisted out of the solve loop as live registers)
             int n_o = n, m_o = m, tid_o = tid;
             asm volatile("" : "+s"(n_o), "+s"(m_o), "+v"(tid_o));
-            const int cj_o = tid_o & 15, rg_o = tid_o >> 4, i16_o = tid_o & 15, kq_o = (tid_o >> 4) & 3, wave_o = tid_o >> 6;
-            if (inst_i[7 * 16 + cj_o] && (b0 + cj_o) < a.B) {
+            const int c_o = tid_o & 15, rg_o = tid_o >> 4, kq_o = (tid_o >> 4) & 3, wave_o = tid_o >> 6;
+            const int oid = inst_i[7 * 16 + c_o] - 1;    // instance that just left this thread's column (-1: none)
+            if (oid >= 0) {
 #pragma unroll
                 for (int e = 0; e < NB; ++e) {
                     const int row = rg_o + 16 * e;
                     if (row < n_o) {
-                        const size_t o = (size_t)(b0 + cj_o) * n_o + row;
+                        const size_t o = (size_t)oid * n_o + row;
                         if (a.out_x) ((float*)a.out_x)[o] = xr[e];
                         a.x[o] = a.warm_starting ? (double)xr[e] : 0.0;
                     }
                 }
-            }
-            if (inst_i[7 * 16 + i16_o] && (b0 + i16_o) < a.B) {
 #pragma unroll
                 for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * (MBW * wave_o + tl) + 4 * kq_o + r;
                         if (row < m_o) {
-                            const size_t o = (size_t)(b0 + i16_o) * m_o + row;
+                            const size_t o = (size_t)oid * m_o + row;
                             if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
                             if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
                             a.z[o] = a.warm_starting ? (double)zz[tl][r] : 0.0;
@@ -603,15 +648,22 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             }
             ri_l = inst_i[4 * 16 + i16];
             set_rho();
-            int nd = 0;
+            int nd = 0, nf = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) nd += inst_i[5 * 16 + j];
-            if (nd == 16) break;                         // every instance of the tile has exited
+            for (int j = 0; j < 16; ++j) {
+                nd += inst_i[5 * 16 + j];
+                nf += inst_i[6 * 16 + j];
+            }
+            if (nd == 16) break;                         // every slot has exited and the queue is empty
             stamp(-1);
+            if (nf) {
+                ph = 4;                                  // load the refilled slots, then A x of their x, then nu for everyone
+            } else {
 #pragma unroll
-            for (int e = 0; e < NB; ++e) V1[MP * 16 + xb3 + 256 * e] = xr[e];    // x rows are already there; keep explicit
-            make_nu();
-            ph = 1;
+                for (int e = 0; e < NB; ++e) V1[MP * 16 + xb3 + 256 * e] = xr[e];    // x rows are already there; keep explicit
+                make_nu();
+                ph = 1;
+            }
         }
         if (ph == 1) stamp(10); else stamp(-1);
     }
@@ -673,13 +725,29 @@ hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStr
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int tiles = (h->B + 15) / 16;
+    // More tiles than CUs (one workgroup per CU: 150 KB of LDS, up to 512 registers per lane): persistent grid, slots
+    // refill from a queue.  (The refill needs every exit to fall on a check, i.e. max_iter on the check grid.)
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, h->device) != hipSuccess) return hipErrorInvalidDevice;
+        ncu = pr.multiProcessorCount;
+    }
+    int grid = tiles;
+    int* queue = nullptr;
+    if (tiles > ncu && h->queue && a.max_iter > 0 && a.check_interval > 0 && a.max_iter % a.check_interval == 0) {
+        grid = ncu;
+        queue = h->queue;
+        e = hipMemsetAsync(queue, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
     if (const char* dg = getenv("RQP_DIAG")) {
         if (dg[0] == '1') {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
             unsigned long long* dbg = nullptr;
-            const size_t cnt = (size_t)tiles * 4 * 12;
+            const size_t cnt = (size_t)grid * 4 * 12;
             if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
             (void)hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            k_admm_mfma<CfgM55, true><<<tiles, CfgM55::NT, lds, s>>>(a, h->W1img, dbg);
+            k_admm_mfma<CfgM55, true><<<grid, CfgM55::NT, lds, s>>>(a, h->W1img, queue, dbg);
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> hb(cnt);
             (void)hipMemcpy(hb.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -687,15 +755,15 @@ hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStr
             static const char* names[11] = {"top wait", "GEMM1", "wait", "d", "wait", "GEMM2", "wait", "x", "wait", "GEMM3+rows", "next"};
             for (int w = 0; w < 4; ++w) {
                 double tot[12] = {0};
-                for (int t = 0; t < tiles; ++t)
-                    for (int e = 0; e < 12; ++e) tot[e] += (double)hb[((size_t)t * 4 + w) * 12 + e];
-                fprintf(stderr, "[rqp diag mfma] wave %d, %.1f iterations/tile, s_memtime ticks per iteration:", w, tot[11] / tiles);
-                for (int e = 0; e < 11; ++e) fprintf(stderr, "  %s %.1f", names[e], tot[e] / tot[11]);
+                for (int t = 0; t < grid; ++t)
+                    for (int e2 = 0; e2 < 12; ++e2) tot[e2] += (double)hb[((size_t)t * 4 + w) * 12 + e2];
+                fprintf(stderr, "[rqp diag mfma] wave %d, %.1f iterations/workgroup, s_memtime ticks per iteration:", w, tot[11] / grid);
+                for (int e2 = 0; e2 < 11; ++e2) fprintf(stderr, "  %s %.1f", names[e2], tot[e2] / tot[11]);
                 fprintf(stderr, "\n");
             }
             return hipGetLastError();
         }
     }
-    k_admm_mfma<CfgM55, false><<<tiles, CfgM55::NT, lds, s>>>(a, h->W1img, nullptr);
+    k_admm_mfma<CfgM55, false><<<grid, CfgM55::NT, lds, s>>>(a, h->W1img, queue, nullptr);
     return hipGetLastError();
 }

@@ -94,3 +94,90 @@ def test_mfma_kernel_matches_resident_and_oracle(B):
     ref2 = O.solve_batch(ctl.H, g2, ctl.A, l2, u2, form="factored", eps_abs=1e-3)
     assert all(s == "solved" for s in r2.info.status)
     assert r2.info.iter.double().mean() <= ref2["iter"].mean()          # warm start: no slower than cold
+
+
+def _solve_with_env(val, ctl, g, l, u, **settings):
+    """setup()+solve() with RQP_MFMA set to `val` (None: unset, i.e. the default dispatch) around setup()."""
+    import os
+    import reluqp.reluqpth as reluqpth
+    old = os.environ.get("RQP_MFMA")
+    if val is None:
+        os.environ.pop("RQP_MFMA", None)
+    else:
+        os.environ["RQP_MFMA"] = val
+    try:
+        m = reluqpth.ReLU_QP()
+        m.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, **settings)
+    finally:
+        if old is None:
+            os.environ.pop("RQP_MFMA", None)
+        else:
+            os.environ["RQP_MFMA"] = old
+    return m, m.solve()
+
+
+def test_mfma_is_default_for_large_shared_batches_full_shape():
+    """BASELINE config-3 shape (nx=12, nu=4, N=20 -> n=80, m=320, the largest tile of the MFMA kernel) at B=1040 (65
+    tiles): the default dispatch picks the MFMA kernel and it agrees with the per-instance resident kernel."""
+    ctl, x0 = _setup("condensed", nx=12, nu=4, N=20, seed=5, B=1040)
+    g, l, u = ctl.qp_vectors(x0)
+    mm, rm = _solve_with_env(None, ctl, g, l, u, eps_abs=1e-3)
+    mr, rr = _solve_with_env("0", ctl, g, l, u, eps_abs=1e-3)
+    assert mm.kernel == "mfma" and mr.kernel.startswith("resident")
+    assert rm.info.status == rr.info.status
+    itm, itr = rm.info.iter.cpu().numpy(), rr.info.iter.cpu().numpy()
+    assert np.mean(itm == itr) >= 0.9
+    same = itm == itr
+    scale = max(1.0, float(rr.x.abs().max()))
+    np.testing.assert_allclose(rm.x.cpu().numpy()[same], rr.x.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.z.cpu().numpy()[same], rr.z.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    assert np.array_equal(rm.info.rho_ind.cpu().numpy()[same], rr.info.rho_ind.cpu().numpy()[same])
+    # solved instances meet the termination test on recomputed residuals
+    pri, dua = mm.compute_residuals(0.1)[:2]                # on the persisted (warm-start) state
+    ok = np.array([s == "solved" for s in rm.info.status])
+    thr = 1e-3 * np.sqrt(ctl.A.shape[0])
+    assert float(pri.cpu().numpy()[ok].max()) < 1.05 * thr
+
+
+@pytest.mark.parametrize("max_iter", [30, 50, 0])
+def test_mfma_max_iter_paths_match_oracle(max_iter):
+    """max_iter off / on the check grid and 0: the max-iter exits of the MFMA kernel (final residual pass, compounded
+    rho estimate when max_iter is a multiple of check_interval) match the oracle's."""
+    ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=3, B=24)
+    g, l, u = ctl.qp_vectors(x0)
+    mm, rm = _solve_with_env("1", ctl, g, l, u, eps_abs=1e-9, max_iter=max_iter)
+    assert mm.kernel == "mfma"
+    ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", eps_abs=1e-9, max_iter=max_iter)
+    assert rm.info.status == ref["status"]
+    assert np.array_equal(rm.info.iter.cpu().numpy(), ref["iter"])
+    scale = max(1.0, np.abs(ref["x"]).max())
+    np.testing.assert_allclose(rm.x.cpu().double().numpy(), ref["x"], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(rm.info.pri_res.cpu().double().numpy(), ref["pri_res"], rtol=5e-2, atol=1e-4)
+    np.testing.assert_allclose(rm.info.rho_estimate.cpu().double().numpy(), ref["rho_estimate"], rtol=0.1)
+
+
+def test_mfma_persistent_grid_refills_slots():
+    """More 16-instance tiles than CUs: the MFMA kernel runs a persistent grid whose slots take the next unsolved instance
+    when theirs exits.  Every instance must come out exactly as from the per-instance resident kernel (same iteration
+    counts -- each instance keeps its own check schedule -- and the same solution), including the ragged tail."""
+    B = 256 * 16 * 2 + 16 * 3 + 5
+    ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=9, B=B)
+    g, l, u = ctl.qp_vectors(x0)
+    mm, rm = _solve_with_env(None, ctl, g, l, u, eps_abs=1e-3)
+    mr, rr = _solve_with_env("0", ctl, g, l, u, eps_abs=1e-3)
+    assert mm.kernel == "mfma" and mr.kernel.startswith("resident")
+    assert rm.info.status == rr.info.status
+    itm, itr = rm.info.iter.cpu().numpy(), rr.info.iter.cpu().numpy()
+    assert itm.min() > 0 and np.mean(itm == itr) >= 0.9
+    same = itm == itr
+    scale = max(1.0, float(rr.x.abs().max()))
+    np.testing.assert_allclose(rm.x.cpu().numpy()[same], rr.x.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.z.cpu().numpy()[same], rr.z.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.y.cpu().numpy()[same], rr.y.cpu().numpy()[same], rtol=0,
+                               atol=2e-3 * max(1.0, float(rr.y.abs().max())))
+    # (the index move at the terminating check is a threshold test on a noise-level estimate: a handful of 8000 differ)
+    assert np.mean(rm.info.rho_ind.cpu().numpy()[same] == rr.info.rho_ind.cpu().numpy()[same]) >= 0.995
+    # a second (warm-started) solve through the same persistent grid: state persisted per instance
+    r2 = mm.solve()
+    assert all(s == "solved" for s in r2.info.status)
+    assert float(r2.info.iter.double().mean()) <= float(rm.info.iter.double().mean())
