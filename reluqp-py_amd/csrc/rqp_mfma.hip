@@ -83,6 +83,8 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     // Columns are SLOTS: slot c of workgroup b starts with instance 16 b + c; with a queue (persistent grid, large batches)
     // a slot whose instance has exited takes the next unsolved instance at the same check, so no MFMA column idles while
     // there is work left and the tile does not wait for its slowest member.
+    unsigned long long t_begin = 0;
+    if constexpr (DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
     const int kmax = a.max_iter;
     const bool refill = queue != nullptr && kmax > 0 && (kmax % a.check_interval) == 0;
 
@@ -101,16 +103,15 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         const int cjp = tp & 15, rgp = tp >> 4;
         return (rgp >> 2) * 64 + ((16 * (rgp & 3) + cjp + 16 * ((rgp >> 2) & 3)) & 63);
     };
+    // (all loads of an image are issued before the first value is pinned: the pin is a use, and a use directly behind
+    //  its load would serialise 225 L2 round trips -- 55 us of prologue, measured)
     float aw1[KS1][NB];              // GEMM1: S[4 (KS1 wave + s) + kq][16 t + i16],  S = [A (MP rows); H' (NP rows)]
     {
         const float* w1 = img + (size_t)wave_u * KS1 * NB * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS1; ++s)
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                aw1[s][t] = w1[(s * NB + t) * 64];
-                asm volatile("" : "+a"(aw1[s][t]));          // resident MFMA A-operands live in the accumulator half (AGPRs)
-            }
+            for (int t = 0; t < NB; ++t) aw1[s][t] = w1[(s * NB + t) * 64];
     }
     float a3[MBW][KS3];              // GEMM3: A[16 (MBW wave + tl) + i16][4 s + kq]
     {
@@ -118,11 +119,16 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 #pragma unroll
         for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
-            for (int s = 0; s < KS3; ++s) {
-                a3[tl][s] = w3[(tl * KS3 + s) * 64];
-                asm volatile("" : "+a"(a3[tl][s]));
-            }
+            for (int s = 0; s < KS3; ++s) a3[tl][s] = w3[(tl * KS3 + s) * 64];
     }
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) asm volatile("" : "+a"(aw1[s][t]));   // resident MFMA A-operands live in the accumulator half (AGPRs)
+#pragma unroll
+    for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+        for (int s = 0; s < KS3; ++s) asm volatile("" : "+a"(a3[tl][s]));
     // GEMM2: K_j[16 t + i16][4 (KS2 wave + s) + kq] in two tagged VGPR blocks
     const float* kimg = img + C::W1_ELEMS + C::W3_ELEMS + (size_t)wave_u * KS2 * NB * 64;
     float kb0[KS2][NB], kb1[KS2][NB];
@@ -209,6 +215,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         }
     };
     stamp(-1);
+    if constexpr (DIAG) t_acc[3] = t_last - t_begin;      // prologue: operand images, settings
 
     while (true) {
         __syncthreads();
@@ -668,6 +675,8 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         if (ph == 1) stamp(10); else stamp(-1);
     }
     if constexpr (DIAG) {
+        stamp(-1);
+        t_acc[4] = t_last - t_begin;                      // whole workgroup
         if (lane == 0)
             for (int e = 0; e < 12; ++e) dbg[((size_t)blockIdx.x * 4 + wave) * 12 + e] = t_acc[e];
     }
@@ -758,8 +767,13 @@ hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStr
                 for (int t = 0; t < grid; ++t)
                     for (int e2 = 0; e2 < 12; ++e2) tot[e2] += (double)hb[((size_t)t * 4 + w) * 12 + e2];
                 fprintf(stderr, "[rqp diag mfma] wave %d, %.1f iterations/workgroup, s_memtime ticks per iteration:", w, tot[11] / grid);
-                for (int e2 = 0; e2 < 11; ++e2) fprintf(stderr, "  %s %.1f", names[e2], tot[e2] / tot[11]);
-                fprintf(stderr, "\n");
+                for (int e2 = 0; e2 < 11; ++e2)
+                    if (e2 != 3 && e2 != 4) fprintf(stderr, "  %s %.1f", names[e2], tot[e2] / tot[11]);
+                double it = 0;
+                for (int e2 = 0; e2 < 11; ++e2)
+                    if (e2 != 3 && e2 != 4) it += tot[e2];
+                fprintf(stderr, "\n[rqp diag mfma] wave %d per workgroup: total %.0f ticks = prologue %.0f + iterations %.0f + load/start/check/exit %.0f\n", w,
+                        tot[4] / grid, tot[3] / grid, it / grid, (tot[4] - tot[3] - it) / grid);
             }
             return hipGetLastError();
         }
