@@ -311,11 +311,19 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     int gb[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) gb[c] = bl_base(lp, KS2 * wave_u, c);
+                    float gk[KS2], pk[KS2][NW];                      // all LDS operands first (one latency, not KS2 of them)
 #pragma unroll
                     for (int s = 0; s < KS2; ++s) {
-                        float d = GV[(KS2 * wave_u + s) * 64 + lp];      // g[4 S + kq][i16]
+                        gk[s] = GV[(KS2 * wave_u + s) * 64 + lp];        // g[4 S + kq][i16]
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) d += part[w * NP * 16 + gb[s & 3] + 64 * s];
+                        for (int w = 0; w < NW; ++w) pk[s][w] = part[w * NP * 16 + gb[s & 3] + 64 * s];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < KS2; ++s) {
+                        float d = gk[s];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) d += pk[s][w];
                         bv[s] = d;
                     }
                 }
@@ -377,11 +385,17 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 int tp = tid;
                 OPQ(tp);
                 const int xb = co_base(tp);
+                float pk[NB][NW];                                     // all partials first (one LDS latency, not NB of them)
+#pragma unroll
+                for (int e = 0; e < NB; ++e)
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) pk[e][w] = part2[w * NP * 16 + xb + 256 * e];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < NB; ++e) {                        // dx = -K d ; x += dx
                     float kd = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) kd += part2[w * NP * 16 + xb + 256 * e];
+                    for (int w = 0; w < NW; ++w) kd += pk[e][w];
                     const float dx = -kd;
                     xr[e] += dx;
                     V3[tp + 256 * e] = dx;                            // [rg + 16 e][cj]
