@@ -35,9 +35,19 @@ struct MfmaCfg {
     static constexpr int KS1 = KT / 4 / NW;           // k-steps of GEMM1 per wave
     static constexpr int KS2 = NB;                    // k-steps of GEMM2 per wave   (NP/4/NW)
     static constexpr int KS3 = NP / 4;                // k-steps of GEMM3 (every wave runs all of them)
+    // Ownership (chosen so that block-triangular A -- condensed MPC -- spreads evenly over the waves and its all-zero
+    // operand tiles can be skipped in groups):
+    //   GEMM1 k-steps are dealt round-robin: local step s of wave w is global k-step NW s + w;
+    //   GEMM3 row tiles are dealt in snake order: local tile tl of wave w is global tile NW tl + (tl odd ? NW-1-w : w).
+    static constexpr int G1 = 5, NG1 = KS1 / G1;      // GEMM1: k-steps per skip group; groups
+    static constexpr int G3 = 5, NG3 = KS3 / G3;      // GEMM3
+    static_assert(KS1 % G1 == 0 && KS3 % G3 == 0, "skip groups");
     // lane-linear operand images (floats): W1 [NW][KS1][NB][64] | W3 [NW][MBW][KS3][64] | K [nrho][NW][KS2][NB][64]
+    // followed by the skip table (ints): g1_start [NW][NB] | g3_count [NW][MBW]
     static constexpr size_t W1_ELEMS = (size_t)NW * KS1 * NB * 64, W3_ELEMS = (size_t)NW * MBW * KS3 * 64;
     static constexpr size_t KJ_ELEMS = (size_t)NW * KS2 * NB * 64;
+    static constexpr size_t META_ELEMS = (size_t)NW * NB + NW * MBW;
+    __host__ __device__ static constexpr int tile_of(int w, int tl) { return NW * tl + ((tl & 1) ? NW - 1 - w : w); }
     static constexpr size_t lds_floats() {
         return (size_t)KT * 16 + NP * 16 + 2 * NW * NP * 16 + 3 * MP * 16 + NB * NT + NP * 16 + NW * 16 * 4 + 16 * 16 * 8 + 64 + 8 * 16;
     }
@@ -64,9 +74,9 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     float* V3 = V1 + KT * 16;                // [NP][16]  dx (x at the start)
     float* part = V3 + NP * 16;              // [NW][NP][16] wave partials of GEMM1 (swizzled rows)
     float* part2 = part + NW * NP * 16;      // [NW][NP][16] wave partials of GEMM2
-    float* LB = part2 + NW * NP * 16;        // [4 MBW][NT] l of the lane's own rows (lane-linear: conflict-free, owner-only)
-    float* UB = LB + MP * 16;                // [4 MBW][NT] u
-    float* ZL = UB + MP * 16;                // [4 MBW][NT] low word of the float-float A x
+    float* LB = part2 + NW * NP * 16;        // [MBW][NT][4] l of the lane's own rows (owner-only, 128-bit per lane and tile)
+    float* UB = LB + MP * 16;                // [MBW][NT][4] u
+    float* ZL = UB + MP * 16;                // [MBW][NT][4] low word of the float-float A x
     float* T3 = ZL + MP * 16;                // [NB][NT]    A' lam of the pending check
     float* GV = T3 + NB * NT;                // [NP][16] g
     float* red = GV + NP * 16;               // [NW][16][4] row-side maxima per (wave, instance)
@@ -133,6 +143,16 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     const float* kimg = img + C::W1_ELEMS + C::W3_ELEMS + (size_t)wave_u * KS2 * NB * 64;
     float kb0[KS2][NB], kb1[KS2][NB];
     int ktag0 = -1, ktag1 = -1;
+    // skip table of this wave (uniform): first k-step group of GEMM1 with a non-zero operand per n tile; number of
+    // leading k-step groups of GEMM3 to run per row tile
+    int g1s[NB], g3c[MBW];
+    {
+        const int* meta = (const int*)(img + C::W1_ELEMS + C::W3_ELEMS + (size_t)a.nrho * C::KJ_ELEMS);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) g1s[t] = __builtin_amdgcn_readfirstlane(meta[wave_u * NB + t]);
+#pragma unroll
+        for (int tl = 0; tl < MBW; ++tl) g3c[tl] = __builtin_amdgcn_readfirstlane(meta[NW * NB + wave_u * MBW + tl]);
+    }
 
     // ---- per-instance scalars and vectors -----------------------------------------------------------------------
     for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
@@ -178,18 +198,21 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     auto make_nu = [&]() __attribute__((always_inline)) {
         int lp = lane;
         OPQ(lp);
-        int nb[4];
+        int nb[2][4];                                     // rows of tile_of(w, tl): base[tl & 1][r] + 1024 tl
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nb[r] = 4 * MBW * wave_u * 64 + dl_base(lp, r);
+        for (int r = 0; r < 4; ++r) {
+            nb[0][r] = 256 * wave_u + dl_base(lp, r);
+            nb[1][r] = 256 * (NW - 1 - wave_u) + dl_base(lp, r);
+        }
 #pragma unroll
         for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float rho = ((eqmask >> (4 * tl + r)) & 1u) ? rho_eq : rho_ne;
-                const float p = (zh[tl][r] - zz[tl][r]) + ZL[(4 * tl + r) * NT + tid];
+                const float p = (zh[tl][r] - zz[tl][r]) + ZL[(tl * NT + tid) * 4 + r];
                 const float lh = lm[tl][r] + rho * p;
                 lm[tl][r] = lh;
-                V1[nb[r] + 256 * tl] = lh + rho * p;
+                V1[nb[tl & 1][r] + 256 * NW * tl] = lh + rho * p;
             }
     };
 
@@ -233,15 +256,15 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * (MBW * wave_o + tl) + 4 * kq_o + r;
+                        const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
                         const bool ok = real && row < m_o;
                         const size_t o = (size_t)(real ? id : 0) * m_o + (row < m_o ? row : 0);
                         zh[tl][r] = 0.f;
-                        ZL[(4 * tl + r) * NT + tp] = 0.f;
+                        ZL[(tl * NT + tp) * 4 + r] = 0.f;
                         zz[tl][r] = ok ? (float)a.z[o] : 0.f;
                         lm[tl][r] = ok ? (float)a.lam[o] : 0.f;
-                        LB[(4 * tl + r) * NT + tp] = ok ? ((const float*)a.l)[o] : 0.f;
-                        UB[(4 * tl + r) * NT + tp] = ok ? ((const float*)a.u)[o] : 0.f;
+                        LB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.l)[o] : 0.f;
+                        UB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.u)[o] : 0.f;
                         const float cv = (row < m_o) ? ((const float*)a.c)[o] : 1.f;
                         if (cv > 1.f) em |= 1u << (4 * tl + r);
                     }
@@ -269,31 +292,35 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         }
         stamp(0);
         if (ph != 0) {                                   // ---------------- GEMM1: wave partial of S' V1
-            f32x4 acc[NB];
-#pragma unroll
-            for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             float bv[KS1];                                           // all B operands first: no LDS latency inside the MFMA stream
             int lp = lane;
             OPQ(lp);
             {
-                int rb[4];
+                const int rb = wave_u * 64 + ((lp + 16 * wave_u) & 63);      // row 4 (NW s + w) + kq: group NW s + w, rotation w
 #pragma unroll
-                for (int c = 0; c < 4; ++c) rb[c] = bl_base(lp, KS1 * wave_u, c);
-#pragma unroll
-                for (int s = 0; s < KS1; ++s) bv[s] = V1[rb[s & 3] + 64 * s];
+                for (int s = 0; s < KS1; ++s) bv[s] = V1[rb + 64 * NW * s];
             }
+            int pb[4];
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) {
+            for (int r = 0; r < 4; ++r) pb[r] = wave_u * NP * 16 + dl_base(lp, r);
 #pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    asm volatile("" ::"a"(aw1[s][t]));              // keep the operand in its AGPR: the MFMA reads it from there
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw1[s][t], bv[s], acc[t], 0, 0, 0);
+            for (int t = 0; t < NB; ++t) {                            // one n tile after the other; its leading all-zero groups are skipped
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};              // (one accumulator live across the group branches: five of them
+                int g0 = g1s[t];                                      //  with the branches in between spill)
+                asm volatile("" : "+s"(g0));                          // opaque: the group tests stay scalar compares in place
+#pragma unroll
+                for (int g = 0; g < C::NG1; ++g) {
+                    if (g >= g0) {
+#pragma unroll
+                        for (int s = g * C::G1; s < (g + 1) * C::G1; ++s) {
+                            asm volatile("" ::"a"(aw1[s][t]));          // keep the operand in its AGPR: the MFMA reads it from there
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw1[s][t], bv[s], acc, 0, 0, 0);
+                        }
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[pb[r] + 256 * t] = acc[r];
             }
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[wave_u * NP * 16 + dl_base(lp, r) + 256 * t] = acc[t][r];
             stamp(1);
             __syncthreads();
             stamp(2);
@@ -418,9 +445,12 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             const bool with_nu = upd && to_chk != 1 && !fin_next;
             int lp = lane;
             OPQ(lp);
-            int nb[4];
+            int nb[2][4];                                 // rows of tile_of(w, tl): base[tl & 1][r] + 1024 tl
 #pragma unroll
-            for (int r = 0; r < 4; ++r) nb[r] = 4 * MBW * wave_u * 64 + dl_base(lp, r);
+            for (int r = 0; r < 4; ++r) {
+                nb[0][r] = 256 * wave_u + dl_base(lp, r);
+                nb[1][r] = 256 * (NW - 1 - wave_u) + dl_base(lp, r);
+            }
             float bv[KS3];
 #pragma unroll
             for (int s = 0; s < KS3; ++s) bv[s] = V3[64 * s + lp];      // dx[4 s + kq][i16]
@@ -432,15 +462,22 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 float pz[4], pl[4], pu[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pz[r] = ZL[(4 * tl + r) * NT + tid];
-                    pl[r] = LB[(4 * tl + r) * NT + tid];
-                    pu[r] = UB[(4 * tl + r) * NT + tid];
+                    pz[r] = ZL[(tl * NT + tid) * 4 + r];
+                    pl[r] = LB[(tl * NT + tid) * 4 + r];         // (4 consecutive floats per lane: one ds_read_b128 per array)
+                    pu[r] = UB[(tl * NT + tid) * 4 + r];
                 }
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                int gc = g3c[tl];
+                asm volatile("" : "+s"(gc));                  // opaque: the group tests stay scalar compares in place
 #pragma unroll
-                for (int s = 0; s < KS3; ++s) {
-                    asm volatile("" ::"a"(a3[tl][s]));          // keep the operand in its AGPR: the MFMA reads it from there
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[tl][s], bv[s], acc, 0, 0, 0);
+                for (int g = 0; g < C::NG3; ++g) {           // trailing all-zero k-step groups of the tile are skipped
+                    if (g < gc) {
+#pragma unroll
+                        for (int s = g * C::G3; s < (g + 1) * C::G3; ++s) {
+                            asm volatile("" ::"a"(a3[tl][s]));  // keep the operand in its AGPR: the MFMA reads it from there
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[tl][s], bv[s], acc, 0, 0, 0);
+                        }
+                    }
                 }
                 {                                            // (start: upd false -- A x accumulates from 0, z stays)
                     float pp[4];
@@ -453,7 +490,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         const float lo = pz[r] + err;
                         const float hi = sgm + lo;
                         const float zlo = lo - (hi - sgm);
-                        ZL[(4 * tl + r) * NT + tid] = zlo;
+                        ZL[(tl * NT + tid) * 4 + r] = zlo;
                         zh[tl][r] = hi;
                         const bool eq = (eqmask >> (4 * tl + r)) & 1u;
                         const float v = hi + (zlo + lm[tl][r] * (eq ? inv_eq : inv_ne));
@@ -470,7 +507,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                             const float rho = ((eqmask >> (4 * tl + r)) & 1u) ? rho_eq : rho_ne;
                             const float lh = lm[tl][r] + rho * pp[r];
                             lm[tl][r] = lh;
-                            V1[nb[r] + 256 * tl] = lh + rho * pp[r];
+                            V1[nb[tl & 1][r] + 256 * NW * tl] = lh + rho * pp[r];
                         }
                     }
                 }
@@ -500,11 +537,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float zlo = ZL[(4 * tl + r) * NT + tid];
+                        const float zlo = ZL[(tl * NT + tid) * 4 + r];
                         v0 = nanmaxf(v0, fabsf((zh[tl][r] - zz[tl][r]) + zlo));
                         v1 = nanmaxf(v1, fabsf(zh[tl][r] + zlo));
                         v2 = nanmaxf(v2, fabsf(zz[tl][r]));
-                        V1[4 * MBW * wave_u * 64 + dl_base(lp, r) + 256 * tl] = lm[tl][r];
+                        V1[256 * C::tile_of(wave_u, tl) + dl_base(lp, r)] = lm[tl][r];
                     }
 #pragma unroll
                 for (int e = 0; e < NB; ++e) V1[MP * 16 + xb + 256 * e] = 0.f;
@@ -526,7 +563,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 #pragma unroll
             for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) V1[4 * MBW * wave_u * 64 + dl_base(lp, r) + 256 * tl] = 0.f;
+                for (int r = 0; r < 4; ++r) V1[256 * C::tile_of(wave_u, tl) + dl_base(lp, r)] = 0.f;
             ph = 3;
         } else {                                         // ph == 3: t2 = H x ; residuals and decisions
             v0 = nanmaxf(v0, __shfl_xor(v0, 16, 64)); v0 = nanmaxf(v0, __shfl_xor(v0, 32, 64));
@@ -657,7 +694,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                 for (int tl = 0; tl < MBW; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * (MBW * wave_o + tl) + 4 * kq_o + r;
+                        const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
                         if (row < m_o) {
                             const size_t o = (size_t)oid * m_o + row;
                             if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
@@ -704,21 +741,21 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 template <class C>
 __global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ img) {
-    constexpr int NB = C::NB, MBW = C::MBW, MP = C::MP, KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3;
+    constexpr int NB = C::NB, MBW = C::MBW, MP = C::MP, KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3, NW = C::NW;
     const size_t total = C::W1_ELEMS + C::W3_ELEMS + (size_t)nrho * C::KJ_ELEMS;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(idx & 63), i16 = l & 15, kq = l >> 4;
         float v = 0.f;
         if (idx < C::W1_ELEMS) {
             const int q = (int)(idx >> 6), t = q % NB, s = (q / NB) % KS1, w = q / (NB * KS1);
-            const int k = 4 * (KS1 * w + s) + kq, i = 16 * t + i16;
+            const int k = 4 * (NW * s + w) + kq, i = 16 * t + i16;
             if (i < n) {
                 if (k < MP) { if (k < m) v = A[(size_t)k * ldn + i]; }
                 else if (k - MP < n) v = Ht[(size_t)(k - MP) * ldn + i];
             }
         } else if (idx < C::W1_ELEMS + C::W3_ELEMS) {
             const int q = (int)((idx - C::W1_ELEMS) >> 6), s = q % KS3, tl = (q / KS3) % MBW, w = q / (KS3 * MBW);
-            const int r = 16 * (MBW * w + tl) + i16, c = 4 * s + kq;
+            const int r = 16 * C::tile_of(w, tl) + i16, c = 4 * s + kq;
             if (r < m && c < n) v = A[(size_t)r * ldn + c];
         } else {
             const size_t o = idx - C::W1_ELEMS - C::W3_ELEMS;
@@ -730,6 +767,29 @@ __global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __rest
     }
 }
 
+// Skip table from the packed images (one thread per entry): g1_start[w][t] = first k-step group of GEMM1 whose operands
+// for n tile t are not all zero (NG1 if none); g3_count[w][tl] = 1 + last k-step group of GEMM3 with a non-zero operand.
+template <class C>
+__global__ void k_meta_mfma(int nrho, const float* __restrict__ img, int* __restrict__ meta) {
+    constexpr int NB = C::NB, MBW = C::MBW, KS1 = C::KS1, KS3 = C::KS3, NW = C::NW;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < NW * NB) {
+        const int w = e / NB, t = e % NB;
+        int first = KS1;
+        for (int s = KS1 - 1; s >= 0; --s)
+            for (int l = 0; l < 64; ++l)
+                if (img[((size_t)(w * KS1 + s) * NB + t) * 64 + l] != 0.f) first = s;
+        meta[e] = first / C::G1;
+    } else if (e < NW * NB + NW * MBW) {
+        const int q = e - NW * NB, w = q / MBW, tl = q % MBW;
+        int last = -1;
+        for (int s = 0; s < KS3; ++s)
+            for (int l = 0; l < 64; ++l)
+                if (img[C::W1_ELEMS + ((size_t)(w * MBW + tl) * KS3 + s) * 64 + l] != 0.f) last = s;
+        meta[e] = (last < 0) ? 0 : last / C::G3 + 1;
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 typedef MfmaCfg<5, 5> CfgM55;        // n <= 80, m <= 320   (linear MPC, N=20, nx=12, nu=4 condensed)
 
@@ -737,10 +797,14 @@ bool rqp_mfma_fits(const rqp_handle* h) {
     return h->esz == 4 && h->dims.shared_mats && h->n <= CfgM55::NP && h->m <= CfgM55::MP && h->nrho <= 64;
 }
 
-size_t rqp_mfma_img_elems(const rqp_handle* h) { return CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS; }
+size_t rqp_mfma_img_elems(const rqp_handle* h) {
+    return CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS + CfgM55::META_ELEMS;
+}
 
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
     k_pack_mfma<CfgM55><<<256, 256, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht, (const float*)h->K, h->W1img);
+    int* meta = (int*)(h->W1img + CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS);
+    k_meta_mfma<CfgM55><<<1, 64, 0, s>>>(h->nrho, h->W1img, meta);
     return hipGetLastError();
 }
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

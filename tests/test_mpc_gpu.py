@@ -181,3 +181,33 @@ def test_mfma_persistent_grid_refills_slots():
     r2 = mm.solve()
     assert all(s == "solved" for s in r2.info.status)
     assert float(r2.info.iter.double().mean()) <= float(rm.info.iter.double().mean())
+
+
+def test_mfma_dense_shared_matrices_with_equality_rows():
+    """Dense random shared (H, A) with equality rows (rho x 1e3 on them) and per-instance (g, l, u): no zero operand
+    tiles to skip, every n/m padding case of the <5,5> tile; MFMA kernel vs the oracle."""
+    from reluqp import utils
+    B, n, n_eq, n_ineq = 40, 70, 10, 190
+    H, g0, A, l0, u0, _ = utils.rand_qp(n, n_eq, n_ineq, seed=5, compute_sol=False, feasible=True)
+    qs = [utils.update_qp(H, A, n_eq, n_ineq, seed=50 + b, compute_sol=False, feasible=True) for b in range(B)]
+    g = np.stack([q[1] for q in qs])
+    l = np.stack([q[3] for q in qs])
+    u = np.stack([q[4] for q in qs])
+
+    class _Ctl:            # duck-typed holder for _solve_with_env
+        pass
+    ctl = _Ctl()
+    ctl.H, ctl.A = H, A
+    mm, rm = _solve_with_env("1", ctl, g, l, u, eps_abs=1e-3)
+    assert mm.kernel == "mfma"
+    ref = O.solve_batch(H, g, A, l, u, form="factored", eps_abs=1e-3)
+    assert rm.info.status == ref["status"]
+    itm = rm.info.iter.cpu().numpy()
+    assert np.mean(itm == ref["iter"]) >= 0.8 and np.all(np.abs(itm - ref["iter"]) <= 75)
+    same = itm == ref["iter"]
+    scale = max(1.0, np.abs(ref["x"]).max())
+    np.testing.assert_allclose(rm.x.cpu().double().numpy()[same], ref["x"][same], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(rm.z.cpu().double().numpy()[same], ref["z"][same], rtol=0, atol=2e-4 * scale)
+    # equality rows are met to the residual tolerance
+    z = rm.z.cpu().double().numpy()
+    assert np.abs(z[:, :n_eq] - l[:, :n_eq]).max() < 1e-2
