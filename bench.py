@@ -86,6 +86,26 @@ def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
     }
 
 
+def pmc_traffic(kernel, args, kern_s):
+    """HBM traffic of the dominant kernel in GB/s from the PMC passes committed under profiles/ (counters cannot be
+    read from inside this process; the passes are separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
+    this same command).  KB units, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md).  None when no profile of this
+    kernel on the default workload is committed."""
+    name = {"resident2": "r1_resident2/pmc_admm_res2.json", "resident": "r1_resident/pmc_admm_resident.json",
+            "generic": "r1_generic/pmc_admm_generic.json"}.get(kernel)
+    default_wl = (args.batch, args.n, args.n_eq, args.n_ineq, args.precision) == (4096, 100, 25, 275, "f32")
+    if name is None or not default_wl:
+        return None, None
+    path = os.path.join(REPO, "profiles", name)
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+        kb = 2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])
+    except (OSError, KeyError, ValueError):
+        return None, None
+    return kb * 1024.0 / kern_s / 1e9, "profiles/" + name + " (bytes per launch / this run's kernel time)"
+
+
 def main():
     args = parse()
     from reluqp import distributed as D
@@ -143,6 +163,7 @@ def main():
         f_iter = 2 * n * n + 4 * m * n
         alg_bytes = sum_iters * b_iter
         achieved = alg_bytes / kern_avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(model.kernel, args, kern_avg_s)
         out = {
             "metric": "QP solves/sec (batch=%d random dense QPs n=%d m=%d per GPU)" % (B, n, m),
             "value": value,
@@ -167,7 +188,7 @@ def main():
             "setup_s": setup_max,
             "setup_plus_solve_qps": tot_qps / (setup_max + step_s),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_admm_%s" % model.kernel, "kernel_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "fp32_valu_tflops": sum_iters * f_iter / kern_avg_s / 1e12,
