@@ -202,6 +202,7 @@ class LinearMPC(object):
         Kt, Adt, Bdt = t(self.K.T), t(self.Ad.T), t(self.Bd.T)
         x = t(np.atleast_2d(x0))
         it_sum = torch.zeros((), device=device, dtype=torch.float64)
+        fresh = False
         for k in range(steps):
             shift = x @ lux
             g, l, u = x @ gx, ladd + shift, uadd + shift
@@ -210,9 +211,17 @@ class LinearMPC(object):
                 self.solver = self.solver or reluqpth.ReLU_QP()
                 self.solver.setup(self.H, g, self.A, l, u, **self.solver_kw)
                 self._ready = True
-            else:
-                self.solver.update(g=g, l=l, u=u)
-            res = self.solver.solve()
+                fresh = True                         # setup() already holds this step's vectors
+            sync = self.solver.synchronous
+            self.solver.synchronous = False          # enqueue only: the steps chain on the stream, no host wait per step
+            try:
+                if fresh:
+                    fresh = False
+                else:
+                    self.solver.update(g=g, l=l, u=u)
+                res = self.solver.solve()
+            finally:
+                self.solver.synchronous = sync
             u0 = res.x[:, :self.nu] - x @ Kt
             x = x @ Adt + u0 @ Bdt
             it_sum += res.info.iter.sum()

@@ -60,6 +60,11 @@ class ReLU_QP(object):
         self._h = None
         self.settings = None
         self.QP = None
+        # True (reference behaviour, reluqpth.py:201-249): update()/solve() return after the device has finished and
+        # fill the *_time fields.  False: they only enqueue on the current stream (batched results are device tensors
+        # ordered on that stream; times read 0) -- closed-loop drivers keep the GPU busy instead of the host waiting.
+        self.synchronous = True
+        self.last_kernel_time = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -190,8 +195,11 @@ class ReLU_QP(object):
                                                 _cabi.ptr(qp.u if u is not None else None), self._stream()),
                         "rqp_update")
             end.record()
-            end.synchronize()
-            self.results.info.update_time = start.elapsed_time(end) / 1000.0
+            if self.synchronous:
+                end.synchronize()
+                self.results.info.update_time = start.elapsed_time(end) / 1000.0
+            else:
+                self.results.info.update_time = 0.0
         return None
 
     def update_settings(self, **kwargs):
@@ -246,9 +254,13 @@ class ReLU_QP(object):
                                                ctypes.byref(ci), self._stream()), "rqp_solve")
             k1.record()
             end.record()
-            end.synchronize()
-            run_time = start.elapsed_time(end) / 1000.0
-            self.last_kernel_time = k0.elapsed_time(k1) / 1000.0   # the ADMM launch alone (HIP events)
+            if self.synchronous:
+                end.synchronize()
+                run_time = start.elapsed_time(end) / 1000.0
+                self.last_kernel_time = k0.elapsed_time(k1) / 1000.0   # the ADMM launch alone (HIP events)
+            else:                        # enqueue only: results are device tensors ordered on the current stream
+                run_time = 0.0
+                self.last_kernel_time = None
         self.last_trace = trace      # [batch][checks][pri, dua, rho_estimate, rho_ind before the move]
         if st.verbose:
             self._print_trace(trace)
@@ -273,8 +285,9 @@ class ReLU_QP(object):
             info.status_code = ints[1]
             info.status = None            # materialised lazily from status_code (classes.Info.status)
             info.rho_ind = ints[2]
-            info.pri_res, info.dua_res = dbls[0].to(prec), dbls[1].to(prec)
-            info.rho_estimate, info.obj_val = dbls[2].to(prec), dbls[3].to(prec)
+            dp = dbls.to(prec)            # one cast for the four per-instance scalars
+            info.pri_res, info.dua_res = dp[0], dp[1]
+            info.rho_estimate, info.obj_val = dp[2], dp[3]
             self.rho_ind = ints[2]
         else:
             self.results.x, self.results.z, self.results.y = x[0], z[0], lam[0]
