@@ -25,6 +25,7 @@
 #include "rqp_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <int NB_, int MBW_>
 struct MfmaCfg {
@@ -252,22 +253,47 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             const bool fresh = inst_i[6 * 16 + c_o] != 0, real = id < a.B;
             if (fresh) {
                 unsigned em = 0;
+                if ((m_o & 3) == 0) {                        // the lane's 4 rows of a tile are contiguous and 16 B aligned:
+#pragma unroll                                               // one sector per (instance, tile, float array)
+                    for (int tl = 0; tl < MBW; ++tl) {
+                        const int row0 = 16 * C::tile_of(wave_o, tl) + 4 * kq_o;
+                        const bool ok = real && row0 < m_o;
+                        const size_t o = ok ? (size_t)id * m_o + row0 : 0;
+                        const f32x4 l4 = *(const f32x4*)((const float*)a.l + o), u4 = *(const f32x4*)((const float*)a.u + o);
+                        const f32x4 c4 = *(const f32x4*)((const float*)a.c + o);
+                        const f64x2 z01 = *(const f64x2*)(a.z + o), z23 = *(const f64x2*)(a.z + o + 2);
+                        const f64x2 y01 = *(const f64x2*)(a.lam + o), y23 = *(const f64x2*)(a.lam + o + 2);
+                        const float zv[4] = {(float)z01[0], (float)z01[1], (float)z23[0], (float)z23[1]};
+                        const float yv[4] = {(float)y01[0], (float)y01[1], (float)y23[0], (float)y23[1]};
 #pragma unroll
-                for (int tl = 0; tl < MBW; ++tl)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
-                        const bool ok = real && row < m_o;
-                        const size_t o = (size_t)(real ? id : 0) * m_o + (row < m_o ? row : 0);
-                        zh[tl][r] = 0.f;
-                        ZL[(tl * NT + tp) * 4 + r] = 0.f;
-                        zz[tl][r] = ok ? (float)a.z[o] : 0.f;
-                        lm[tl][r] = ok ? (float)a.lam[o] : 0.f;
-                        LB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.l)[o] : 0.f;
-                        UB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.u)[o] : 0.f;
-                        const float cv = (row < m_o) ? ((const float*)a.c)[o] : 1.f;
-                        if (cv > 1.f) em |= 1u << (4 * tl + r);
+                        for (int r = 0; r < 4; ++r) {
+                            zh[tl][r] = 0.f;
+                            ZL[(tl * NT + tp) * 4 + r] = 0.f;
+                            zz[tl][r] = ok ? zv[r] : 0.f;
+                            lm[tl][r] = ok ? yv[r] : 0.f;
+                            LB[(tl * NT + tp) * 4 + r] = ok ? l4[r] : 0.f;
+                            UB[(tl * NT + tp) * 4 + r] = ok ? u4[r] : 0.f;
+                            if (ok && c4[r] > 1.f) em |= 1u << (4 * tl + r);
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
+                            const bool ok = real && row < m_o;
+                            const size_t o = (size_t)(real ? id : 0) * m_o + (row < m_o ? row : 0);
+                            zh[tl][r] = 0.f;
+                            ZL[(tl * NT + tp) * 4 + r] = 0.f;
+                            zz[tl][r] = ok ? (float)a.z[o] : 0.f;
+                            lm[tl][r] = ok ? (float)a.lam[o] : 0.f;
+                            LB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.l)[o] : 0.f;
+                            UB[(tl * NT + tp) * 4 + r] = ok ? ((const float*)a.u)[o] : 0.f;
+                            const float cv = (row < m_o) ? ((const float*)a.c)[o] : 1.f;
+                            if (cv > 1.f) em |= 1u << (4 * tl + r);
+                        }
+                }
                 eqmask = em;
             }
             const int xb = co_base(tp);
@@ -690,19 +716,38 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         a.x[o] = a.warm_starting ? (double)xr[e] : 0.0;
                     }
                 }
+                if ((m_o & 3) == 0) {                        // 16 B / 32 B stores: the lane's 4 rows of a tile are contiguous
 #pragma unroll
-                for (int tl = 0; tl < MBW; ++tl)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
-                        if (row < m_o) {
-                            const size_t o = (size_t)oid * m_o + row;
-                            if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
-                            if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
-                            a.z[o] = a.warm_starting ? (double)zz[tl][r] : 0.0;
-                            a.lam[o] = a.warm_starting ? (double)lm[tl][r] : 0.0;
+                    for (int tl = 0; tl < MBW; ++tl) {
+                        const int row0 = 16 * C::tile_of(wave_o, tl) + 4 * kq_o;
+                        if (row0 < m_o) {
+                            const size_t o = (size_t)oid * m_o + row0;
+                            const f32x4 z4 = {zz[tl][0], zz[tl][1], zz[tl][2], zz[tl][3]};
+                            const f32x4 y4 = {lm[tl][0], lm[tl][1], lm[tl][2], lm[tl][3]};
+                            if (a.out_z) *(f32x4*)((float*)a.out_z + o) = z4;
+                            if (a.out_lam) *(f32x4*)((float*)a.out_lam + o) = y4;
+                            const bool ws = a.warm_starting != 0;
+                            *(f64x2*)(a.z + o) = (f64x2){ws ? (double)z4[0] : 0.0, ws ? (double)z4[1] : 0.0};
+                            *(f64x2*)(a.z + o + 2) = (f64x2){ws ? (double)z4[2] : 0.0, ws ? (double)z4[3] : 0.0};
+                            *(f64x2*)(a.lam + o) = (f64x2){ws ? (double)y4[0] : 0.0, ws ? (double)y4[1] : 0.0};
+                            *(f64x2*)(a.lam + o + 2) = (f64x2){ws ? (double)y4[2] : 0.0, ws ? (double)y4[3] : 0.0};
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int tl = 0; tl < MBW; ++tl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * C::tile_of(wave_o, tl) + 4 * kq_o + r;
+                            if (row < m_o) {
+                                const size_t o = (size_t)oid * m_o + row;
+                                if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
+                                if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
+                                a.z[o] = a.warm_starting ? (double)zz[tl][r] : 0.0;
+                                a.lam[o] = a.warm_starting ? (double)lm[tl][r] : 0.0;
+                            }
+                        }
+                }
             }
             ri_l = inst_i[4 * 16 + i16];
             set_rho();

@@ -187,7 +187,7 @@ def test_mfma_dense_shared_matrices_with_equality_rows():
     """Dense random shared (H, A) with equality rows (rho x 1e3 on them) and per-instance (g, l, u): no zero operand
     tiles to skip, every n/m padding case of the <5,5> tile; MFMA kernel vs the oracle."""
     from reluqp import utils
-    B, n, n_eq, n_ineq = 40, 70, 10, 190
+    B, n, n_eq, n_ineq = 40, 70, 10, 189          # m = 199: not a multiple of 4 (scalar load/store path)
     H, g0, A, l0, u0, _ = utils.rand_qp(n, n_eq, n_ineq, seed=5, compute_sol=False, feasible=True)
     qs = [utils.update_qp(H, A, n_eq, n_ineq, seed=50 + b, compute_sol=False, feasible=True) for b in range(B)]
     g = np.stack([q[1] for q in qs])
