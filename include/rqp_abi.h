@@ -114,6 +114,14 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
  * (reluqpth.py:177) and have no entry point here.  State is untouched.          */
 int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void* stream);
 
+/* Parametric form of ReLU_QP.update for linear MPC (the x0 update of the reference's driver,
+ * loose_code/RandomLinMPC.py / SURVEY.md Appendix C, evaluated on the device in one pass):
+ *   g[b] = Gg p[b],   l[b] = l0 + Glu p[b],   u[b] = u0 + Glu p[b]
+ * p [batch][np] (np <= 64), Gg [n][np], Glu [m][np], l0/u0 [m], all device pointers in the
+ * handle's dtype.  Same effect as rqp_update with those vectors; state is untouched.       */
+int rqp_update_affine(rqp_handle* h, const void* p, int32_t np, const void* Gg, const void* Glu,
+                      const void* l0, const void* u0, void* stream);
+
 /* ReLU_QP.update_settings (reluqpth.py:185-199): only max_iter, eps_abs and
  * check_interval may change after setup; a difference in any other field returns
  * RQP_ERR_ARG (the reference raises ValueError).                                  */

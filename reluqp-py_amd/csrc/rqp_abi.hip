@@ -245,6 +245,15 @@ int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void*
     return RQP_OK;
 }
 
+int rqp_update_affine(rqp_handle* h, const void* p, int32_t np, const void* Gg, const void* Glu, const void* l0,
+                      const void* u0, void* stream) {
+    if (!h || !p || !Gg || !Glu || !l0 || !u0 || np <= 0 || np > 64) return RQP_ERR_ARG;
+    if (!h->is_setup) return RQP_ERR_STATE;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, rqp_launch_affine_update(h, p, np, Gg, Glu, l0, u0, (hipStream_t)stream));
+    return RQP_OK;
+}
+
 int rqp_update_settings(rqp_handle* h, const rqp_settings* s) {
     if (!h || !s) return RQP_ERR_ARG;
     const rqp_settings& o = h->st;

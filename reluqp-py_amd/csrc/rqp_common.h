@@ -83,6 +83,8 @@ struct SetupArgs {
 
 // launchers (defined in the .hip files); return hipError_t of the launch
 hipError_t rqp_launch_pack(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_affine_update(const rqp_handle* h, const void* p, int np, const void* Gg, const void* Glu,
+                                    const void* l0, const void* u0, hipStream_t s);
 hipError_t rqp_launch_vec_update(const rqp_handle* h, const void* g, const void* l, const void* u, hipStream_t s);
 hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
 hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s);

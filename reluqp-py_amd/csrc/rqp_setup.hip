@@ -86,6 +86,45 @@ hipError_t rqp_launch_vec_update(const rqp_handle* h, const void* g, const void*
     return hipGetLastError();
 }
 
+// g[b] = Gg p[b], l[b] = l0 + Glu p[b], u[b] = u0 + Glu p[b]  (rqp_update_affine: the MPC x0 update in one pass).
+// One thread per output element; p[b] is read through the cache by the n + m threads of its instance, the maps
+// (a few KB) stay in L1/L2.  Sums run over j in order (plain T arithmetic).
+template <typename T>
+__global__ void k_affine_update(int B, int n, int m, int np, const T* __restrict__ p, const T* __restrict__ Gg,
+                                const T* __restrict__ Glu, const T* __restrict__ l0, const T* __restrict__ u0,
+                                T* __restrict__ gd, T* __restrict__ ld, T* __restrict__ ud) {
+    const size_t per = (size_t)n + m, total = (size_t)B * per;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / per;
+        const int i = (int)(idx - b * per);
+        const T* pb = p + b * np;
+        const T* row = (i < n) ? Gg + (size_t)i * np : Glu + (size_t)(i - n) * np;
+        T acc = (T)0;
+        for (int j = 0; j < np; ++j) acc += row[j] * pb[j];
+        if (i < n) {
+            gd[b * n + i] = acc;
+        } else {
+            const int r = i - n;
+            ld[b * m + r] = l0[r] + acc;
+            ud[b * m + r] = u0[r] + acc;
+        }
+    }
+}
+
+hipError_t rqp_launch_affine_update(const rqp_handle* h, const void* p, int np, const void* Gg, const void* Glu,
+                                    const void* l0, const void* u0, hipStream_t s) {
+    const size_t total = (size_t)h->B * (h->n + h->m);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (h->esz == 4)
+        k_affine_update<float><<<blocks, 256, 0, s>>>(h->B, h->n, h->m, np, (const float*)p, (const float*)Gg, (const float*)Glu,
+                                                      (const float*)l0, (const float*)u0, (float*)h->g, (float*)h->l, (float*)h->u);
+    else
+        k_affine_update<double><<<blocks, 256, 0, s>>>(h->B, h->n, h->m, np, (const double*)p, (const double*)Gg,
+                                                       (const double*)Glu, (const double*)l0, (const double*)u0, (double*)h->g,
+                                                       (double*)h->l, (double*)h->u);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------ gram
 // G[r][c] = sum_k c_k A[k][r] A[k][c] in float64.  One workgroup = one 64x64 output tile of
 // one matrix; 16x16 threads, 4x4 register tile each; A staged through LDS 16 rows at a time.

@@ -15,7 +15,7 @@ STATUS_STR = {0: "solved", 1: "max_iters_reached", -1: "unsolved"}
 
 # every symbol include/rqp_abi.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
-    "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_settings",
+    "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_affine", "rqp_update_settings",
     "rqp_warm_start", "rqp_clear_primal_dual", "rqp_solve", "rqp_iterate", "rqp_compute_residuals",
     "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
     "rqp_last_error", "rqp_version",
@@ -77,6 +77,7 @@ def load():
         "rqp_create": (ctypes.c_int, [ctypes.POINTER(H), ctypes.POINTER(Dims), ctypes.POINTER(CSettings), ctypes.c_int]),
         "rqp_setup": (ctypes.c_int, [H, vp, vp, vp, vp, vp, vp]),
         "rqp_update": (ctypes.c_int, [H, vp, vp, vp, vp]),
+        "rqp_update_affine": (ctypes.c_int, [H, vp, ctypes.c_int32, vp, vp, vp, vp, vp]),
         "rqp_update_settings": (ctypes.c_int, [H, ctypes.POINTER(CSettings)]),
         "rqp_warm_start": (ctypes.c_int, [H, vp, vp, vp, ctypes.c_int, dbl, vp]),
         "rqp_clear_primal_dual": (ctypes.c_int, [H, vp]),

@@ -203,10 +203,11 @@ class LinearMPC(object):
         x = t(np.atleast_2d(x0))
         it_sum = torch.zeros((), device=device, dtype=torch.float64)
         fresh = False
+        gmap, lumap = gx.T.contiguous(), lux.T.contiguous()       # [n, nx], [m, nx]
         for k in range(steps):
-            shift = x @ lux
-            g, l, u = x @ gx, ladd + shift, uadd + shift
             if not self._ready:
+                shift = x @ lux
+                g, l, u = x @ gx, ladd + shift, uadd + shift
                 import reluqp.reluqpth as reluqpth
                 self.solver = self.solver or reluqpth.ReLU_QP()
                 self.solver.setup(self.H, g, self.A, l, u, **self.solver_kw)
@@ -217,8 +218,8 @@ class LinearMPC(object):
             try:
                 if fresh:
                     fresh = False
-                else:
-                    self.solver.update(g=g, l=l, u=u)
+                else:                                # g = G x, l/u = l_add/u_add + LU x in one device pass
+                    self.solver.update_affine(x, gmap, lumap, ladd, uadd)
                 res = self.solver.solve()
             finally:
                 self.solver.synchronous = sync

@@ -202,6 +202,36 @@ class ReLU_QP(object):
                 self.results.info.update_time = 0.0
         return None
 
+    def update_affine(self, p, g_map, lu_map, l0, u0):
+        """Parametric update for linear MPC, evaluated on the device in one pass (C-ABI rqp_update_affine):
+        ``g = p @ g_map.T``, ``l = l0 + p @ lu_map.T``, ``u = u0 + p @ lu_map.T`` with p [batch, np] (the current
+        states x0), g_map [n, np], lu_map [m, np], l0/u0 [m].  Equivalent to ``update(g=..., l=..., u=...)`` with those
+        vectors (the x0 update of the reference's RandomLinMPC driver); ``self.QP.g/l/u`` are not refreshed."""
+        self._need_setup()
+        qp, st = self.QP, self.settings
+        if not qp.batched:
+            raise ValueError("update_affine needs a batched problem")
+        p = self._to_dev(p, (qp.batch, _as_tensor(p).shape[-1]), "p")
+        npar = p.shape[-1]
+        g_map = self._to_dev(g_map, (qp.nx, npar), "g_map")
+        lu_map = self._to_dev(lu_map, (qp.nc, npar), "lu_map")
+        l0 = self._to_dev(l0, (qp.nc,), "l0")
+        u0 = self._to_dev(u0, (qp.nc,), "u0")
+        with torch.cuda.device(st.device):
+            if self.synchronous:
+                start, end = self._events()
+                start.record()
+            _cabi.check(self._h, _cabi.load().rqp_update_affine(self._h, _cabi.ptr(p), int(npar), _cabi.ptr(g_map),
+                                                                  _cabi.ptr(lu_map), _cabi.ptr(l0), _cabi.ptr(u0),
+                                                                  self._stream()), "rqp_update_affine")
+            if self.synchronous:
+                end.record()
+                end.synchronize()
+                self.results.info.update_time = start.elapsed_time(end) / 1000.0
+            else:
+                self.results.info.update_time = 0.0
+        return None
+
     def update_settings(self, **kwargs):
         """
         Update ReLU-QP solver settings
@@ -233,11 +263,12 @@ class ReLU_QP(object):
         st, qp = self.settings, self.QP
         dev, B, n, m = st.device, qp.batch, qp.nx, qp.nc
         with torch.cuda.device(dev):
-            start, end = self._events()
-            start.record()
-            x = torch.empty(B, n, device=dev, dtype=st.precision)
-            z = torch.empty(B, m, device=dev, dtype=st.precision)
-            lam = torch.empty(B, m, device=dev, dtype=st.precision)
+            timed = self.synchronous
+            if timed:
+                start, end = self._events()
+                start.record()
+            xzl = torch.empty(B * (n + 2 * m), device=dev, dtype=st.precision)      # one allocation, three contiguous views
+            x, z, lam = xzl[:B * n].view(B, n), xzl[B * n:B * (n + m)].view(B, m), xzl[B * (n + m):].view(B, m)
             ints = torch.empty(3, B, device=dev, dtype=torch.int32)
             dbls = torch.empty(4, B, device=dev, dtype=torch.float64)
             trace, cap = None, 0
@@ -248,13 +279,14 @@ class ReLU_QP(object):
                              pri_res=dbls[0].data_ptr(), dua_res=dbls[1].data_ptr(),
                              rho_estimate=dbls[2].data_ptr(), obj_val=dbls[3].data_ptr(),
                              trace=trace.data_ptr() if trace is not None else None, trace_cap=cap, reserved=0)
-            k0, k1 = self._events()
-            k0.record()
+            if timed:
+                k0, k1 = self._events()
+                k0.record()
             _cabi.check(self._h, lib.rqp_solve(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
                                                ctypes.byref(ci), self._stream()), "rqp_solve")
-            k1.record()
-            end.record()
-            if self.synchronous:
+            if timed:
+                k1.record()
+                end.record()
                 end.synchronize()
                 run_time = start.elapsed_time(end) / 1000.0
                 self.last_kernel_time = k0.elapsed_time(k1) / 1000.0   # the ADMM launch alone (HIP events)

@@ -211,3 +211,32 @@ def test_mfma_dense_shared_matrices_with_equality_rows():
     # equality rows are met to the residual tolerance
     z = rm.z.cpu().double().numpy()
     assert np.abs(z[:, :n_eq] - l[:, :n_eq]).max() < 1e-2
+
+
+@pytest.mark.parametrize("prec", [torch.float32, torch.float64])
+def test_update_affine_matches_update(prec):
+    """rqp_update_affine (g = G x0, l/u = l_add/u_add + LU x0 on the device) leaves the solver in the same state as
+    update(g, l, u) with host-built vectors: identical iteration counts, solutions within rounding."""
+    import reluqp.reluqpth as reluqpth
+    ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=4, B=48)
+    dev = torch.device("cuda:0")
+    g, l, u = ctl.qp_vectors(x0)
+    x1 = 0.8 * x0 + 0.05
+    g1, l1, u1 = ctl.qp_vectors(x1)
+    ma, mb = reluqpth.ReLU_QP(), reluqpth.ReLU_QP()
+    for mdl in (ma, mb):
+        mdl.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=prec, eps_abs=1e-4)
+        mdl.solve()
+    ma.update(g=g1, l=l1, u=u1)
+    mb.update_affine(x1, ctl.g_x0, ctl.lu_x0, ctl.l_add, ctl.u_add)
+    ra, rb = ma.solve(), mb.solve()
+    assert ra.info.status == rb.info.status
+    ita, itb = ra.info.iter.cpu().numpy(), rb.info.iter.cpu().numpy()
+    assert np.mean(ita == itb) >= 0.95
+    same = ita == itb
+    tol = 1e-9 if prec == torch.float64 else 2e-5
+    scale = max(1.0, float(ra.x.abs().max()))
+    np.testing.assert_allclose(rb.x.cpu().double().numpy()[same], ra.x.cpu().double().numpy()[same], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(rb.z.cpu().double().numpy()[same], ra.z.cpu().double().numpy()[same], rtol=0, atol=tol * scale)
+    with pytest.raises(ValueError):
+        mb.update_affine(x1[:, :3], ctl.g_x0, ctl.lu_x0, ctl.l_add, ctl.u_add)
