@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--closed-loop", type=int, default=0, help="number of closed-loop control steps (0: cold solves)")
+    ap.add_argument("--graph", action="store_true", help="closed loop: capture the control step in a HIP graph and replay it")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs an MI355X"
@@ -56,10 +57,14 @@ def main():
         xw, _ = ctl.simulate_device(x0, 1, dev, prec)   # setup + first (cold) solve, untimed
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        xf, mean_it = ctl.simulate_device(xw.cpu().numpy(), args.closed_loop, dev, prec)
+        if args.graph:
+            xf, mean_it = ctl.simulate_graph(xw.cpu().numpy(), args.closed_loop, dev, prec)
+        else:
+            xf, mean_it = ctl.simulate_device(xw.cpu().numpy(), args.closed_loop, dev, prec)
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
-        out = {"bench": "closed-loop linear MPC (update + warm-started solve per step), maps on device", "form": args.form,
+        out = {"bench": "closed-loop linear MPC (update + warm-started solve per step), maps on device" +
+               (", control step replayed from a HIP graph" if args.graph else ""), "form": args.form,
                "batch": args.batch, "n": n, "m": m, "control_steps": args.closed_loop,
                "qp_solves_per_sec": args.batch * args.closed_loop / el, "ms_per_control_step": el / args.closed_loop * 1e3,
                "mean_iters_per_solve": mean_it, "final_state_norm_over_initial":

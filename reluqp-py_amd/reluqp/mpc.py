@@ -228,6 +228,42 @@ class LinearMPC(object):
             it_sum += res.info.iter.sum()
         return x, float(it_sum) / (steps * x.shape[0])
 
+    def simulate_graph(self, x0, steps, device, dtype):
+        """simulate_device with the control step (x0 update, warm-started solve, plant step) captured ONCE in a HIP graph
+        and replayed ``steps`` times: no host work per step at all (launch-bound small batches gain the most).
+        The solver must be set up (run simulate_device for one step first).  Returns as simulate_device."""
+        import torch
+        assert self.form == "condensed" and self._ready
+        t = lambda a: torch.as_tensor(a, device=device, dtype=dtype)
+        gmap, lumap, ladd, uadd = t(self.g_x0).contiguous(), t(self.lu_x0).contiguous(), t(self.l_add), t(self.u_add)
+        Kt, Adt, Bdt = t(self.K.T), t(self.Ad.T), t(self.Bd.T)
+        x = t(np.atleast_2d(x0)).clone()                      # static buffer: the graph reads and rewrites it in place
+        it_sum = torch.zeros((), device=device, dtype=torch.float64)
+        sync = self.solver.synchronous
+        self.solver.synchronous = False
+        try:
+            def step():
+                self.solver.update_affine(x, gmap, lumap, ladd, uadd)
+                res = self.solver.solve()
+                u0 = res.x[:, :self.nu] - x @ Kt
+                x.copy_(x @ Adt + u0 @ Bdt)
+                it_sum.add_(res.info.iter.sum())
+            side = torch.cuda.Stream(device=device)           # warm-up on a side stream, as torch's capture rules ask
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream(device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            done = 1                                          # the warm-up ran one step (capturing only records)
+            for _ in range(max(0, steps - done)):
+                graph.replay()
+        finally:
+            self.solver.synchronous = sync
+        torch.cuda.synchronize(device)
+        return x, float(it_sum) / (max(steps, done) * x.shape[0])
+
     def simulate(self, x0, steps, noise=0.0, seed=0):
         """Closed loop x+ = Ad x + Bd u (+ noise); returns (states [steps+1, B, nx], inputs, iteration counts)."""
         rs = np.random.RandomState(seed)
