@@ -326,29 +326,53 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     // rows owned by this thread: tid (all waves) and tid + 256 (wave 0 only)
     // do_a: A x += sum of the 4 wave partials ; z = clamp(A x + lam/rho)      (completes state k)
     // do_b: lam_hat, nu of the NEXT iteration                                  (advances lam)
-    auto row_pass = [&](bool init, bool do_a, bool do_b) {
-        for (int i = tid; i < M; i += NT) {
-            double zt = zt64[i], z = z64[i];
+    // Rows i = tid (+ NT for the lanes that own a second row: with M = NT + 64 that is exactly wave 0).  The two rows of a
+    // lane are processed in ONE pass with their loads issued together and their (latency-bound, float64) chains
+    // interleaved, instead of two passes back to back -- wave 0 was 520 cycles behind the others at the next barrier.
+    auto row_body = [&](auto nr, bool init, bool do_a, bool do_b) __attribute__((always_inline)) {
+        constexpr int R = decltype(nr)::value;
+        double zt[R], z[R], lmv[R];
+        float adx[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = tid + q * NT;
+            zt[q] = zt64[i];
+            z[q] = z64[i];
+            lmv[q] = lam64[i];
+            if (init || do_a) adx[q] = ((part[i] + part[M + i]) + part[2 * M + i]) + part[3 * M + i];
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = tid + q * NT;
             if (init || do_a) {
-                const float adx = ((part[i] + part[M + i]) + part[2 * M + i]) + part[3 * M + i];
-                zt = (init ? 0.0 : zt) + (double)adx;
-                zt64[i] = zt;
+                zt[q] = (init ? 0.0 : zt[q]) + (double)adx[q];
+                zt64[i] = zt[q];
             }
             if (do_a) {
-                const double v = zt + lam64[i] * inv64[i];
-                z = v;                                                 // torch.clamp: NaN stays NaN
-                if (v < (double)lT[i]) z = (double)lT[i];
-                if (v > (double)uT[i]) z = (double)uT[i];
-                z64[i] = z;
+                const double v = zt[q] + lmv[q] * inv64[i];
+                z[q] = v;                                              // torch.clamp: NaN stays NaN
+                if (v < (double)lT[i]) z[q] = (double)lT[i];
+                if (v > (double)uT[i]) z[q] = (double)uT[i];
+                z64[i] = z[q];
             }
             if (do_b) {
                 const double rv = (double)rv32[i];
-                const double pr = zt - z;
-                const double lh = lam64[i] + rv * pr;
+                const double pr = zt[q] - z[q];
+                const double lh = lmv[q] + rv * pr;
                 lam64[i] = lh;
                 nu[i] = (float)(lh + rv * pr);
             }
         }
+    };
+    auto row_pass = [&](bool init, bool do_a, bool do_b) __attribute__((always_inline)) {
+        if constexpr (M > NT) {
+            static_assert(M <= 2 * NT, "at most two rows per lane");
+            if (tid + NT < M) {
+                row_body(std::integral_constant<int, 2>{}, init, do_a, do_b);
+                return;
+            }
+        }
+        if (tid < M) row_body(std::integral_constant<int, 1>{}, init, do_a, do_b);
     };
 
     unsigned long long t_last = 0, t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
