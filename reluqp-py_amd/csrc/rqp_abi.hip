@@ -223,9 +223,11 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         h->kernel_name = want_v1 ? "resident" : "resident2";
     }
     // shared-(H,A) batches large enough to fill the chip with 16-instance tiles go to the MFMA kernel
+    // (crossover measured on the condensed-MPC shape: 1024 -> resident 1.7x faster, 2048 -> even cold / MFMA 1.3x closed loop,
+    //  3072 -> MFMA 1.35x / 1.8x)
     const char* mf = getenv("RQP_MFMA");                  // "0": never, "1": whenever it fits
     h->use_mfma = rqp_mfma_fits(h) && !(force && force[0] == '1') && !(mf && mf[0] == '0') &&
-                  (h->B >= 1024 || (mf && mf[0] == '1'));
+                  (h->B >= 2048 || (mf && mf[0] == '1'));      // below ~2k instances the per-instance kernel still wins (measured)
     if (h->use_mfma) {
         HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));

@@ -117,9 +117,9 @@ def _solve_with_env(val, ctl, g, l, u, **settings):
 
 
 def test_mfma_is_default_for_large_shared_batches_full_shape():
-    """BASELINE config-3 shape (nx=12, nu=4, N=20 -> n=80, m=320, the largest tile of the MFMA kernel) at B=1040 (65
+    """BASELINE config-3 shape (nx=12, nu=4, N=20 -> n=80, m=320, the largest tile of the MFMA kernel) at B=2064 (129
     tiles): the default dispatch picks the MFMA kernel and it agrees with the per-instance resident kernel."""
-    ctl, x0 = _setup("condensed", nx=12, nu=4, N=20, seed=5, B=1040)
+    ctl, x0 = _setup("condensed", nx=12, nu=4, N=20, seed=5, B=2064)
     g, l, u = ctl.qp_vectors(x0)
     mm, rm = _solve_with_env(None, ctl, g, l, u, eps_abs=1e-3)
     mr, rr = _solve_with_env("0", ctl, g, l, u, eps_abs=1e-3)
