@@ -697,6 +697,15 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     }
                 }
                 inst_i[7 * 16 + j] = newly;
+                // Columns without a live instance keep iterating on garbage; give them the rho index of a live column so that
+                // they never cost a GEMM2 pass or a K refill of their own (their results are already out).
+                const bool live = inst_i[5 * 16 + j] == 0;
+                const int ri_now = inst_i[4 * 16 + j];
+                const unsigned long long lm16 = __ballot(live);      // lanes 0..15 = the 16 columns
+                if (lm16) {
+                    const int ri_live = __shfl(ri_now, __ffsll((long long)lm16) - 1, 64);
+                    if (!live) inst_i[4 * 16 + j] = ri_live;
+                }
             }
             __syncthreads();
             // instances that just finished: x, z, lam out (update_results :278-305) and the persistent state
