@@ -2,19 +2,21 @@
 // dimension of fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the fp32 vector rate, one
 // instruction = 1024 MACs instead of 64 -- the instruction overhead of the per-instance kernels disappears).
 //
-// One 256-thread workgroup (4 waves, one per SIMD, up to 512 VGPRs each) iterates a TILE of 16 instances:
-//   GEMM1  d  = [A; H']' [nu; x] + g     (n x 16)   K split over the 4 waves, partials meet in LDS
+// One 256-thread workgroup (4 waves, one per SIMD, up to 512 VGPRs each) iterates a TILE of 16 instance SLOTS:
+//   GEMM1  d  = [A; H']' [nu; x] + g     (n x 16)   K split over the 4 waves (k-steps dealt round-robin), partials meet in LDS
 //   GEMM2  dx = -K_j d                   (n x 16)   K split; per-column choice of K_j (each instance has its own
 //                                                   rho index): one masked pass per distinct index in the tile
-//   GEMM3  A dx                          (m x 16)   M split: wave w owns m/4 rows and their row state
+//   GEMM3  A dx                          (m x 16)   M split: row tiles dealt in snake order; a wave owns the row state of its tiles
 // The matrices are MFMA A-operands.  [A; H'] (GEMM1) and A (GEMM3) stay in registers for the whole solve: 225 per lane,
 // in the accumulator half of the unified register file (AGPRs, pinned with empty asm constraints -- left alone hipcc
 // keeps MFMA sources in arch VGPRs and spills them).  K_j blocks (25 per lane) sit in two tagged VGPR blocks that
 // refill from L2.  All operands are read from lane-linear images packed at setup (k_pack_mfma), so every load is one
-// coalesced 256 B row per wave.  B-operands (nu, x, d, dx) pass through LDS in [k][16] layout.  Per-instance state
-// lives in registers in the MFMA D layout (lane = instance column, 4 rows per 16x16 tile): z, lam in float32 and A x
-// as a float-float pair (the role float64 plays in the other kernels: only A x needs the extra bits, DESIGN.md
-// section 2); l, u, g wait in LDS.
+// coalesced 256 B row per wave; groups of all-zero operands (block-triangular MPC matrices, padding) are skipped
+// (k_meta_mfma).  B-operands (nu, x, dx) and the K-split partials pass through LDS in [k][16] layout.  Per-instance
+// state lives in registers in the MFMA D layout (lane = slot column, 4 rows per 16x16 tile): z, lam in float32 and the
+// high word of A x; its low word (A x is a float-float pair -- the role float64 plays in the other kernels: only A x
+// needs the extra bits), l, u and g wait in LDS.
+// Large batches run a persistent grid: a slot whose instance exits at a check takes the next unsolved instance.
 // Register-allocation notes (hipcc 7.2): rare-path sizes/offsets go through opaque copies, otherwise LICM hoists
 // hundreds of loop-invariant addresses and predicates out of the solve loop and the kernel spills.
 // Same recurrence, check logic and quirk dispositions as k_admm_generic (rqp_admm.hip); reference line citations there.
@@ -58,14 +60,14 @@ __device__ __forceinline__ float nanmaxf(float a, float b) {          // NaN-pro
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
 }
 
-// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles each wave spends per segment.
 // Swizzle of the [row][16] LDS arrays that are written in the MFMA D layout (lane = column, rows 16 T + 4 kq + r) and read
 // in the MFMA B layout (lane kq reads row 4 S + kq) -- V1, part, part2: each group of 4 rows (64 floats = one pass over
 // the banks) is rotated by 16 * (group & 3):
 //      addr(row, col) = (row >> 2) * 64 + ((16 * (row & 3) + col + 16 * ((row >> 2) & 3)) & 63)
 // which makes BOTH access patterns conflict-free (unrotated, the four kq of a D-layout write hit the same bank).
 // The kernel forms these addresses as base + compile-time offset (dl_base / bl_base / co_base below).
-
+//
+// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles each wave spends per segment.
 template <class C, bool DIAG>
 __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* __restrict__ img, int* __restrict__ queue, unsigned long long* __restrict__ dbg) {
     constexpr int NB = C::NB, MBW = C::MBW, NT = C::NT, NW = C::NW, NP = C::NP, MP = C::MP, KT = C::KT;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                                              //          5 done, 6 column to (re)load, 7 id + 1 of an instance that just exited
     int* inst_i = (int*)inst;
 
-    const int n = a.n, m = a.m, ldn = a.ldn;
+    const int n = a.n, m = a.m;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;       // MFMA lane coordinates
     const int cj = tid & 15, rg = tid >> 4;          // column-owner coordinates: instance cj, rows rg + 16 e
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     };
     // (all loads of an image are issued before the first value is pinned: the pin is a use, and a use directly behind
     //  its load would serialise 225 L2 round trips -- 55 us of prologue, measured)
-    float aw1[KS1][NB];              // GEMM1: S[4 (KS1 wave + s) + kq][16 t + i16],  S = [A (MP rows); H' (NP rows)]
+    float aw1[KS1][NB];              // GEMM1: S[4 (NW s + wave) + kq][16 t + i16],  S = [A (MP rows); H' (NP rows)]
     {
         const float* w1 = img + (size_t)wave_u * KS1 * NB * 64 + lane;
 #pragma unroll
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 #pragma unroll
             for (int t = 0; t < NB; ++t) aw1[s][t] = w1[(s * NB + t) * 64];
     }
-    float a3[MBW][KS3];              // GEMM3: A[16 (MBW wave + tl) + i16][4 s + kq]
+    float a3[MBW][KS3];              // GEMM3: A[16 tile_of(wave, tl) + i16][4 s + kq]
     {
         const float* w3 = img + C::W1_ELEMS + (size_t)wave_u * MBW * KS3 * 64 + lane;
 #pragma unroll
@@ -824,7 +826,7 @@ __global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __rest
 // Skip table from the packed images (one thread per entry): g1_start[w][t] = first k-step group of GEMM1 whose operands
 // for n tile t are not all zero (NG1 if none); g3_count[w][tl] = 1 + last k-step group of GEMM3 with a non-zero operand.
 template <class C>
-__global__ void k_meta_mfma(int nrho, const float* __restrict__ img, int* __restrict__ meta) {
+__global__ void k_meta_mfma(const float* __restrict__ img, int* __restrict__ meta) {
     constexpr int NB = C::NB, MBW = C::MBW, KS1 = C::KS1, KS3 = C::KS3, NW = C::NW;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < NW * NB) {
@@ -858,7 +860,7 @@ size_t rqp_mfma_img_elems(const rqp_handle* h) {
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
     k_pack_mfma<CfgM55><<<256, 256, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht, (const float*)h->K, h->W1img);
     int* meta = (int*)(h->W1img + CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS);
-    k_meta_mfma<CfgM55><<<1, 64, 0, s>>>(h->nrho, h->W1img, meta);
+    k_meta_mfma<CfgM55><<<1, 64, 0, s>>>(h->W1img, meta);
     return hipGetLastError();
 }
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

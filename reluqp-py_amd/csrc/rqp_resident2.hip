@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
                                                       const float* __restrict__ Kpack,
                                                       const float* __restrict__ Hpack, unsigned long long* dbg) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, NW = C::NW, RP = C::RP, KP = C::KP;
-    constexpr int CW = C::CW, N = C::N, M = C::M, ND = C::ND, SW = C::SW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HP = C::HP, HR = C::HR, H1 = C::H1, H2 = C::H2;
+    constexpr int CW = C::CW, M = C::M, ND = C::ND, SW = C::SW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HP = C::HP, HR = C::HR, H1 = C::H1, H2 = C::H2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* zt64 = (double*)smem_raw;                    // [M] A x        (row i owned by thread i % 256)
     double* lam64 = zt64 + M;
@@ -603,7 +603,7 @@ template <class C>
 __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
                             float* __restrict__ Hpack) {
-    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR, HE2 = C::HE2;
+    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR;
     const int mat = blockIdx.y;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
