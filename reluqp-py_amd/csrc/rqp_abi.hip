@@ -76,11 +76,13 @@ void free_ws(rqp_handle* h) {
     h->resident = false;
     h->res_kind = 0;
     h->use_mfma = false;
+    h->use_wave = false;
     h->kernel_name = "generic";
 }
 
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
     if (h->use_mfma && a.mode == 0) return rqp_launch_solve_mfma(h, a, s);
+    if (h->use_wave && a.mode == 0) return rqp_launch_solve_wave(h, a, s);
     if (h->resident && h->res_kind == 2) return rqp_launch_solve_res2(h, a, s);
     if (h->resident) return rqp_launch_solve_resident(h, a, s);
     return rqp_launch_solve_generic(h, a, s);
@@ -234,6 +236,10 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, rqp_launch_pack_mfma(h, s));
         h->kernel_name = "mfma";
     }
+    // small problems: one wavefront per instance (solve() only; iterate / residuals stay on the kernels above)
+    const char* wv = getenv("RQP_WAVE");                  // "0": never
+    h->use_wave = !h->use_mfma && rqp_wave_fits(h) && !(force && force[0] == '1') && !(wv && wv[0] == '0');
+    if (h->use_wave) h->kernel_name = "wave";
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
 }

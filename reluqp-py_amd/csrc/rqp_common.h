@@ -46,6 +46,7 @@ struct rqp_handle {
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
     bool resident = false;
     int res_kind = 0;             // 1: rqp_resident.hip (row-block layout), 2: rqp_resident2.hip (column block per wave)
+    bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
@@ -104,6 +105,9 @@ bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+
+bool rqp_wave_fits(const rqp_handle* h);
+hipError_t rqp_launch_solve_wave(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 bool rqp_mfma_fits(const rqp_handle* h);
 size_t rqp_mfma_img_elems(const rqp_handle* h);

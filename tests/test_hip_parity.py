@@ -28,17 +28,20 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _model(H, g, A, l, u, precision=torch.float64, generic=False, **kw):
-    """generic=True forces the streaming kernel (k_admm_generic) where the resident one would fit."""
+def _model(H, g, A, l, u, precision=torch.float64, generic=False, wave=True, **kw):
+    """generic=True forces the streaming kernel (k_admm_generic) where a resident one would fit; wave=False keeps small
+    problems off the one-wavefront-per-instance kernel (they then run on the small resident tile)."""
     import os
     import reluqp.reluqpth as reluqpth
     m = reluqpth.ReLU_QP()
     m.collect_trace = True
     os.environ["RQP_FORCE_GENERIC"] = "1" if generic else "0"
+    os.environ["RQP_WAVE"] = "1" if wave else "0"
     try:
         m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
     finally:
         os.environ["RQP_FORCE_GENERIC"] = "0"
+        os.environ.pop("RQP_WAVE", None)
     if generic or precision == torch.float64:
         assert m.kernel == "generic"
     return m
@@ -90,7 +93,7 @@ def test_g1_ladder_and_kernel_loaded(golden):
     m = _model(*_qp(g))
     assert np.array_equal(_np(m.layers.rhos), g["rhos"])
     assert m.rho_ind == int(g["rho_ind0"]) == 7
-    assert m.kernel in ("generic", "resident", "resident2")
+    assert m.kernel in ("generic", "resident", "resident2", "wave")
     m2 = _model(*_qp(g), adaptive_rho=False)
     assert np.array_equal(_np(m2.layers.rhos), g["rhos_noadapt"])
     m3 = _model(*_qp(g), rho=0.4, rho_min=1e-3, rho_max=1e3, adaptive_rho_tolerance=3)
@@ -314,7 +317,10 @@ def test_resident_equals_generic_fp32():
 
 
 @pytest.mark.parametrize("n,n_eq,n_ineq,kernel", [
-    (32, 8, 56, "resident2"),      # exactly the small tile (n=32, m=64)
+    (32, 8, 56, "wave"),           # exactly the one-wavefront kernel's caps (n=32, m=64)
+    (32, 8, 56, "resident2"),      # ... and the small resident tile of the same size (RQP_WAVE=0)
+    (31, 7, 50, "wave"),           # n, m not multiples of 4 / of the half-wave split
+    (5, 2, 9, "wave"),
     (33, 8, 57, "resident2"),      # one past it -> mid tile
     (56, 14, 114, "resident2"),    # exactly the mid tile (n=56, m=128)
     (57, 14, 115, "resident2"),    # one past it -> big tile
@@ -326,7 +332,7 @@ def test_tile_boundaries_fp32(n, n_eq, n_ineq, kernel):
     """Padding paths of the resident tiles: sizes on and just past every tile limit give oracle results."""
     B = 3
     H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=900 + n, feasible=True)
-    m = _model(H, g, A, l, u, precision=torch.float32)
+    m = _model(H, g, A, l, u, precision=torch.float32, wave=(kernel == "wave"))
     assert m.kernel == kernel
     res = m.solve()
     ref = O.solve_batch(H, g, A, l, u, form="factored")
