@@ -34,6 +34,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (f32 in / f32 acc) dense peak
 
 
 def parse():
@@ -49,6 +50,9 @@ def parse():
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--workload", choices=["random_qp", "mpc"], default="random_qp",
+                    help="random_qp: the headline metric's workload (default); mpc: BASELINE config 3, batch of condensed "
+                         "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A")
     return ap.parse_args()
 
 
@@ -65,9 +69,10 @@ def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
     iters = 0
     done = 0
     t0 = time.perf_counter()
-    while done < H.shape[0] and (time.perf_counter() - t0) < budget_s:
+    shared = H.ndim == 2                      # linear MPC: one (H, A) for the whole batch
+    while done < g.shape[0] and (time.perf_counter() - t0) < budget_s:
         qp = O.OracleQP(form="W", quirks=False)
-        qp.setup(H[done], g[done], A[done], l[done], u[done], eps_abs=eps_abs)
+        qp.setup(H if shared else H[done], g[done], A if shared else A[done], l[done], u[done], eps_abs=eps_abs)
         r = qp.solve()
         t_setup += qp.info.setup_time
         t_solve += r.info.run_time
@@ -93,7 +98,7 @@ def pmc_traffic(kernel, args, kern_s):
     kernel on the default workload is committed."""
     name = {"resident2": "r1_resident2/pmc_admm_res2.json", "resident": "r1_resident/pmc_admm_resident.json",
             "generic": "r1_generic/pmc_admm_generic.json"}.get(kernel)
-    default_wl = (args.batch, args.n, args.n_eq, args.n_ineq, args.precision) == (4096, 100, 25, 275, "f32")
+    default_wl = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision) == ("random_qp", 4096, 100, 25, 275, "f32")
     if name is None or not default_wl:
         return None, None
     path = os.path.join(REPO, "profiles", name)
@@ -123,9 +128,18 @@ def main():
     # weak scaling: the job is world*B instances; rank r owns the contiguous shard [r*B, (r+1)*B)
     start, size = D.shard_range(world * B, rank, world)
     assert size == B
-    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + start, feasible=True)
+    if args.workload == "mpc":
+        from reluqp import mpc
+        Adyn, Bdyn = mpc.random_plant(12, 4, seed=0)                      # one plant, the batch is the initial states
+        ctl = mpc.LinearMPC(Adyn, Bdyn, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
+        x0 = np.random.RandomState(args.seed0 + 1 + rank).randn(B, 12)
+        H, A = ctl.H, ctl.A                                               # shared by the batch (un-batched)
+        g, l, u = ctl.qp_vectors(x0)
+        n, m = H.shape[0], A.shape[0]
+    else:
+        H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + start, feasible=True)
     # inputs resident in HBM in the working dtype before anything is timed (host->device of 655 MB is data loading)
-    Hd, gd, Ad, ld, ud = (torch.from_numpy(t).to(device=dev, dtype=prec) for t in (H, g, A, l, u))
+    Hd, gd, Ad, ld, ud = (torch.from_numpy(np.ascontiguousarray(t)).to(device=dev, dtype=prec) for t in (H, g, A, l, u))
     torch.cuda.synchronize(dev)
     model = reluqpth.ReLU_QP()
     t0 = time.perf_counter()
@@ -164,8 +178,17 @@ def main():
         alg_bytes = sum_iters * b_iter
         achieved = alg_bytes / kern_avg_s / 1e9
         traffic, traffic_src = pmc_traffic(model.kernel, args, kern_avg_s)
+        if args.workload == "mpc":
+            wl = ("batch=%d/GPU condensed linear-MPC QPs (horizon 20, nx=12, nu=4: n=%d, m=%d), H and A shared by the "
+                  "batch, random initial states seed %d.., eps_abs=%g, cold start, reference defaults"
+                  % (B, n, m, args.seed0 + 1, args.eps_abs))
+            metric = "QP solves/sec (batch=%d linear-MPC QPs n=%d m=%d per GPU)" % (B, n, m)
+        else:
+            wl = ("batch=%d/GPU random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds %d.., eps_abs=%g, cold "
+                  "start, reference defaults" % (B, n, m, args.n_eq, args.seed0, args.eps_abs))
+            metric = "QP solves/sec (batch=%d random dense QPs n=%d m=%d per GPU)" % (B, n, m)
         out = {
-            "metric": "QP solves/sec (batch=%d random dense QPs n=%d m=%d per GPU)" % (B, n, m),
+            "metric": metric,
             "value": value,
             "unit": "QP/s",
             "n_gpus": world,
@@ -177,9 +200,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": "batch=%d/GPU random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds "
-                                   "%d.., eps_abs=%g, cold start, reference defaults" %
-                                   (B, n, m, args.n_eq, args.seed0, args.eps_abs),
+            "config": {"workload": wl,
                        "global_batch": int(tot_qps), "parallelism": "batch-split x%d, no collectives" % world,
                        "kernel": model.kernel},
             "admm_iters_per_sec": tot_iters / step_s,
@@ -194,6 +215,14 @@ def main():
                          "fp32_valu_tflops": sum_iters * f_iter / kern_avg_s / 1e12,
                          "fp32_valu_frac": sum_iters * f_iter / kern_avg_s / 1e12 / FP32_VALU_PEAK_TFLOPS},
         }
+        if model.kernel == "mfma":
+            # the batch is the N axis of fp32 MFMA GEMMs: price against the fp32 matrix peak with the dense
+            # algorithmic flops 2*(2mn + 2n^2) per instance-iteration ("k_admm_mfma")
+            tf = sum_iters * f_iter / kern_avg_s / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "k_admm_mfma", "kernel_ms": kern_avg_s * 1e3,
+                               "algorithmic_flops_per_launch": sum_iters * f_iter}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(H, g, A, l, u, args.eps_abs, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
