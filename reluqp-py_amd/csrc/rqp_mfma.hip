@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     }
                 }
                 unsigned long long todo = __ballot(lane < 16);       // one representative lane per instance column
+                bool first_pass = true;
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
                     const int j = __builtin_amdgcn_readlane(ri_l, src);
@@ -421,11 +422,17 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 #pragma unroll
                             for (int t = 0; t < NB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb1[s][t], bv[s], acc[t], 0, 0, 0);
                     }
-                    const bool mine = (ri_l == j);
+                    if (first_pass) {                                // (usually the only one: every column shares one K_j)
 #pragma unroll
-                    for (int t = 0; t < NB; ++t)
+                        for (int t = 0; t < NB; ++t) sel[t] = acc[t];
+                        first_pass = false;
+                    } else {
+                        const bool mine = (ri_l == j);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sel[t][r] = mine ? acc[t][r] : sel[t][r];
+                        for (int t = 0; t < NB; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sel[t][r] = mine ? acc[t][r] : sel[t][r];
+                    }
                     todo &= ~__ballot(lane < 16 && ri_l == j);
                 }
 #pragma unroll
@@ -788,6 +795,8 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
             for (int e = 0; e < 12; ++e) dbg[((size_t)blockIdx.x * 4 + wave) * 12 + e] = t_acc[e];
     }
 }
+
+#undef OPQ
 
 // ---------------------------------------------------------------------------- packing
 // Lane-linear operand images (lane l of an MFMA A-operand holds element [l & 15][l >> 4] of its 16 x 4 tile):
