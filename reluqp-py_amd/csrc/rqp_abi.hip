@@ -210,7 +210,11 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     const char* force = getenv("RQP_FORCE_GENERIC");
     const char* kind = getenv("RQP_RESIDENT");            // "1": first resident layout (A/B runs); default: layout 2
     const bool want_v1 = kind && kind[0] == '1';
-    if (!(force && force[0] == '1') && (want_v1 ? rqp_resident_fits(h) : rqp_res2_fits(h))) {
+    // small problems: one wavefront per instance (solve() only; iterate / residuals then run on the streaming kernel, so
+    // the resident images are not built at all)
+    const char* wv = getenv("RQP_WAVE");                  // "0": never
+    const bool want_wave = rqp_wave_fits(h) && !(force && force[0] == '1') && !(wv && wv[0] == '0') && !want_v1;
+    if (!want_wave && !(force && force[0] == '1') && (want_v1 ? rqp_resident_fits(h) : rqp_res2_fits(h))) {
         size_t ae, ke, he;
         if (want_v1)
             rqp_resident_pack_elems(h, &ae, &ke, &he);
@@ -236,9 +240,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, rqp_launch_pack_mfma(h, s));
         h->kernel_name = "mfma";
     }
-    // small problems: one wavefront per instance (solve() only; iterate / residuals stay on the kernels above)
-    const char* wv = getenv("RQP_WAVE");                  // "0": never
-    h->use_wave = !h->use_mfma && rqp_wave_fits(h) && !(force && force[0] == '1') && !(wv && wv[0] == '0');
+    h->use_wave = want_wave && !h->use_mfma;
     if (h->use_wave) h->kernel_name = "wave";
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
