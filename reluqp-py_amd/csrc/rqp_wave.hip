@@ -11,156 +11,154 @@
 // Vectors cross between the roles through 640 B of LDS read with wave-uniform-per-half addresses (broadcast reads,
 // ds_read_b128); the two halves of a column meet with one cross-half shuffle.
 // Same recurrence (oracle/reluqp_oracle.py: forward_refine), check logic and quirk dispositions as k_admm_generic
-// (rqp_admm.hip; reference line citations there); float32 products, float64 state.
+// (rqp_admm.hip; reference line citations there); products in T (float: packed FMAs; double: the reference's default
+// precision, same layout with twice the registers), float64 state.
 #include "rqp_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int WNC = 32, WMC = 64;      // caps: n <= 32, m <= 64
 
-__device__ __forceinline__ float wtmax(float a, float b) {            // torch.max / norm(inf): NaN propagates
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// 16-byte chunks (global and LDS accesses) and element pairs (register storage, fma granularity)
+template <typename T>
+struct WV;
+template <>
+struct WV<float> {
+    typedef f32x4 chunk;
+    typedef f32x2 pair;
+    static constexpr int W = 4, OCC = 3;      // elements per chunk; waves per SIMD (<= 168 VGPRs)
+};
+template <>
+struct WV<double> {
+    typedef f64x2 chunk;
+    typedef f64x2 pair;
+    static constexpr int W = 2, OCC = 1;      // matrices alone are 192 VGPRs
+};
+
+template <typename T>
+__device__ __forceinline__ T wtmax(T a, T b) {                        // torch.max / norm(inf): NaN propagates
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
 }
-__device__ __forceinline__ float wave_tmax(float v) {
+template <typename T>
+__device__ __forceinline__ T wave_tmax(T v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = wtmax(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off >= 1; off >>= 1) v = wtmax(v, (T)__shfl_xor(v, off, 64));
     return v;
 }
 
 }   // namespace
 
-__global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 waves per SIMD: <= 168 VGPRs
-    __shared__ __attribute__((aligned(16))) float nuL[WMC];            // nu (lam at a check) by row
-    __shared__ __attribute__((aligned(16))) float xL[WNC];             // x by column
-    __shared__ __attribute__((aligned(16))) float dL[WNC];             // d by column
-    __shared__ __attribute__((aligned(16))) float dxL[WNC];            // dx by column
+template <typename T>
+__global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
+    typedef typename WV<T>::chunk chunk;
+    typedef typename WV<T>::pair pair;
+    constexpr int W = WV<T>::W, PW = W / 2;                            // elements / pairs per 16-byte chunk
+    __shared__ __attribute__((aligned(16))) T nuL[WMC];                // nu (lam at a check) by row
+    __shared__ __attribute__((aligned(16))) T xL[WNC];                 // x by column
+    __shared__ __attribute__((aligned(16))) T dL[WNC];                 // d by column
+    __shared__ __attribute__((aligned(16))) T dxL[WNC];                // dx by column
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
     const int r = lane, c = lane & 31, h = lane >> 5;
     const bool rok = r < m, cok = c < n;
-    const float* A = (const float*)a.A + (size_t)b * a.sA;
-    const float* At = (const float*)a.At + (size_t)b * a.sAt;
-    const float* Ht = (const float*)a.Ht + (size_t)b * a.sH;
-    const float* Kb = (const float*)a.K + (size_t)b * a.sK;
+    const T* A = (const T*)a.A + (size_t)b * a.sA;
+    const T* At = (const T*)a.At + (size_t)b * a.sAt;
+    const T* Ht = (const T*)a.Ht + (size_t)b * a.sH;
+    const T* Kb = (const T*)a.K + (size_t)b * a.sK;
 
-    // ---- matrices into registers (leading dimensions are multiples of 4 floats, padding is zero)
-    // (kept as float pairs: every product runs on v_pk_fma_f32 -- two accumulators, even / odd elements, added at the end)
-    f32x2 Ar[WNC / 2], Atc[16], Hc[8], Kc[8];
+    // ---- matrices into registers (leading dimensions are multiples of 16 bytes, padding is zero); kept as element pairs:
+    //      every product runs on pair FMAs (v_pk_fma_f32 for float) -- two accumulators, even / odd elements, added at the end
+    pair Ar[WNC / 2], Atc[16], Hc[8], Kc[8];
+    auto load_row = [&](pair* dst, int len, const T* src, bool ok, int ld_left) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < WNC / 4; ++q) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (rok && 4 * q < ldn) v = *(const f32x4*)(A + (size_t)r * ldn + 4 * q);
-        Ar[2 * q] = (f32x2){v[0], v[1]};
-        Ar[2 * q + 1] = (f32x2){v[2], v[3]};
-    }
+        for (int q = 0; q < len / W; ++q) {
+            chunk v;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (cok && 32 * h + 4 * q < ldm) v = *(const f32x4*)(At + (size_t)c * ldm + 32 * h + 4 * q);
-        Atc[2 * q] = (f32x2){v[0], v[1]};
-        Atc[2 * q + 1] = (f32x2){v[2], v[3]};
-    }
+            for (int e = 0; e < W; ++e) v[e] = (T)0;
+            if (ok && W * q < ld_left) v = *(const chunk*)(src + W * q);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (cok && 16 * h + 4 * q < ldn) v = *(const f32x4*)(Ht + (size_t)c * ldn + 16 * h + 4 * q);   // sym(H): row c = column c
-        Hc[2 * q] = (f32x2){v[0], v[1]};
-        Hc[2 * q + 1] = (f32x2){v[2], v[3]};
-    }
-    int ri = a.rho_ind[b];
-    auto load_K = [&]() {
-        const float* Kj = Kb + (size_t)ri * n * ldn;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && 16 * h + 4 * q < ldn) v = *(const f32x4*)(Kj + (size_t)c * ldn + 16 * h + 4 * q);
-            Kc[2 * q] = (f32x2){v[0], v[1]};
-            Kc[2 * q + 1] = (f32x2){v[2], v[3]};
+            for (int e = 0; e < PW; ++e) dst[q * PW + e] = (pair){v[2 * e], v[2 * e + 1]};
         }
+    };
+    load_row(Ar, WNC, A + (size_t)r * ldn, rok, ldn);                        // row r of A
+    load_row(Atc, 32, At + (size_t)c * ldm + 32 * h, cok, ldm - 32 * h);     // rows 32 h .. of column c
+    load_row(Hc, 16, Ht + (size_t)c * ldn + 16 * h, cok, ldn - 16 * h);      // sym(H): row c = column c
+    int ri = a.rho_ind[b];
+    auto load_K = [&]() __attribute__((always_inline)) {
+        load_row(Kc, 16, Kb + ((size_t)ri * n + c) * ldn + 16 * h, cok, ldn - 16 * h);
     };
     load_K();
 
     // ---- vectors and state
-    const float gc = cok ? ((const float*)a.g)[(size_t)b * n + c] : 0.f;
-    const float lr = rok ? ((const float*)a.l)[(size_t)b * m + r] : 0.f;
-    const float ur = rok ? ((const float*)a.u)[(size_t)b * m + r] : 0.f;
-    const float cr = rok ? ((const float*)a.c)[(size_t)b * m + r] : 1.f;
+    const T gc = cok ? ((const T*)a.g)[(size_t)b * n + c] : (T)0;
+    const T lr = rok ? ((const T*)a.l)[(size_t)b * m + r] : (T)0;
+    const T ur = rok ? ((const T*)a.u)[(size_t)b * m + r] : (T)0;
+    const T cr = rok ? ((const T*)a.c)[(size_t)b * m + r] : (T)1;
     double x = cok ? a.x[(size_t)b * n + c] : 0.0;
     double z = rok ? a.z[(size_t)b * m + r] : 0.0;
     double lam = rok ? a.lam[(size_t)b * m + r] : 0.0;
-    float rv = (float)a.rhos[ri] * cr;
+    T rv = (T)a.rhos[ri] * cr;
     double inv = 1.0 / (double)rv;
 
     // products: column role reads by-row vectors (nuL) / by-column vectors (xL, dL); row role reads dxL
-    auto at_times = [&](f32x2 acc) __attribute__((always_inline)) {     // acc + sum_j A[32 h + j][c] * nuL[32 h + j]  (pairwise)
+    auto dot = [&](const pair* M, int len, const T* vec, pair acc) __attribute__((always_inline)) {   // acc + sum M[j] vec[j], pairwise
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 v = *(const f32x4*)(nuL + 32 * h + 4 * q);
-            acc = __builtin_elementwise_fma(Atc[2 * q], (f32x2){v[0], v[1]}, acc);
-            acc = __builtin_elementwise_fma(Atc[2 * q + 1], (f32x2){v[2], v[3]}, acc);
+        for (int q = 0; q < len / W; ++q) {
+            const chunk v = *(const chunk*)(vec + W * q);
+#pragma unroll
+            for (int e = 0; e < PW; ++e) acc = __builtin_elementwise_fma(M[q * PW + e], (pair){v[2 * e], v[2 * e + 1]}, acc);
         }
         return acc;
     };
-    auto half16 = [&](const f32x2 (&M)[8], const float* vec, f32x2 acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *(const f32x4*)(vec + 16 * h + 4 * q);
-            acc = __builtin_elementwise_fma(M[2 * q], (f32x2){v[0], v[1]}, acc);
-            acc = __builtin_elementwise_fma(M[2 * q + 1], (f32x2){v[2], v[3]}, acc);
-        }
-        return acc;
-    };
-    auto a_times = [&]() __attribute__((always_inline)) {               // sum_c A[r][c] * dxL[c]
-        f32x2 acc = {0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < WNC / 4; ++q) {
-            const f32x4 v = *(const f32x4*)(dxL + 4 * q);
-            acc = __builtin_elementwise_fma(Ar[2 * q], (f32x2){v[0], v[1]}, acc);
-            acc = __builtin_elementwise_fma(Ar[2 * q + 1], (f32x2){v[2], v[3]}, acc);
-        }
+    const pair zero2 = {(T)0, (T)0};
+    auto at_times = [&](pair acc) __attribute__((always_inline)) { return dot(Atc, 32, nuL + 32 * h, acc); };   // + A[32 h..][c]' nu[32 h..]
+    auto h_times = [&](pair acc) __attribute__((always_inline)) { return dot(Hc, 16, xL + 16 * h, acc); };     // + H[c][16 h..] x[16 h..]
+    auto k_times = [&]() __attribute__((always_inline)) { return dot(Kc, 16, dL + 16 * h, zero2); };           // K[c][16 h..] d[16 h..]
+    auto a_times = [&]() __attribute__((always_inline)) {                                                      // A[r][:] dx
+        const pair acc = dot(Ar, WNC, dxL, zero2);
         return acc[0] + acc[1];
     };
-    const f32x2 zero2 = {0.f, 0.f};
-    auto fold = [&](f32x2 v) __attribute__((always_inline)) { return v[0] + v[1]; };
-    auto both_halves = [&](float v) __attribute__((always_inline)) { return v + __shfl_xor(v, 32, 64); };
+    auto fold = [&](pair v) __attribute__((always_inline)) { return v[0] + v[1]; };
+    auto both_halves = [&](T v) __attribute__((always_inline)) { return v + (T)__shfl_xor(v, 32, 64); };
 
     // (by-column LDS vectors are written by BOTH halves of a column -- same value, same address: no exec-masked region
     //  in the loop.  With the writes under `if (h == 0)` hipcc 7.2 moved the following full-wave ds_reads of the same
     //  array into the masked block, leaving lanes 32..63 with stale registers.)
     // A x of the incoming state
-    dxL[c] = (float)x;
-    xL[c] = (float)x;
+    dxL[c] = (T)x;
+    xL[c] = (T)x;
     double zt = (double)a_times();
 
     bool converged = false;
     int iters = 0;
-    float pri = 0.f, dua = 0.f, hx = 0.f;
-    float rho_est = (float)a.rhos[ri];                                  // :211
-    const float tolT = (float)a.tol;
+    T pri = (T)0, dua = (T)0, hx = (T)0;
+    T rho_est = (T)a.rhos[ri];                                          // :211
+    const T tolT = (T)a.tol;
     const int kmax = a.max_iter;
 
     // compute_residuals (:307-318) on the current state; leaves H x of the column in hx
-    auto residuals = [&](float rho_carry, float& o_pri, float& o_dua) -> float {
-        nuL[r] = (float)lam;
-        const float t3 = both_halves(fold(at_times(zero2)));            // A' lam
-        hx = both_halves(fold(half16(Hc, xL, zero2)));                  // H x
-        const float v0 = wave_tmax(fabsf((float)(zt - z)));
-        const float v1 = wave_tmax(fabsf((float)zt));
-        const float v2 = wave_tmax(fabsf((float)z));
-        const float v3 = wave_tmax(fabsf(hx + t3 + gc));
-        const float v4 = wave_tmax(fabsf(hx));
-        const float v5 = wave_tmax(fabsf(t3));
-        const float v6 = wave_tmax(fabsf(gc));
+    auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
+        nuL[r] = (T)lam;
+        const T t3 = both_halves(fold(at_times(zero2)));                // A' lam
+        hx = both_halves(fold(h_times(zero2)));                         // H x
+        const T v0 = wave_tmax((T)fabs((T)(zt - z)));
+        const T v1 = wave_tmax((T)fabs((T)zt));
+        const T v2 = wave_tmax((T)fabs((T)z));
+        const T v3 = wave_tmax((T)fabs(hx + t3 + gc));
+        const T v4 = wave_tmax((T)fabs(hx));
+        const T v5 = wave_tmax((T)fabs(t3));
+        const T v6 = wave_tmax((T)fabs(gc));
         o_pri = v0;
         o_dua = v3;
-        const float num = v0 / wtmax(v1, v2);                           // :315
-        const float den = v3 / wtmax(wtmax(v4, v5), v6);                // :316
-        float est = rho_carry * sqrtf(num / den);                       // :317
-        if (est < (float)a.rho_min) est = (float)a.rho_min;             // torch.clamp: NaN stays NaN
-        if (est > (float)a.rho_max) est = (float)a.rho_max;
+        const T num = v0 / wtmax(v1, v2);                               // :315
+        const T den = v3 / wtmax(wtmax(v4, v5), v6);                    // :316
+        T est = rho_carry * (T)sqrt(num / den);                         // :317
+        if (est < (T)a.rho_min) est = (T)a.rho_min;                     // torch.clamp: NaN stays NaN
+        if (est > (T)a.rho_max) est = (T)a.rho_max;
         return est;
     };
 
@@ -169,15 +167,15 @@ __global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 wa
             const double p = zt - z;
             const double lh = lam + (double)rv * p;
             lam = lh;
-            nuL[r] = (float)(lh + (double)rv * p);
+            nuL[r] = (T)(lh + (double)rv * p);
         }
         {                                                               // column role: d = H x + g + A' nu ; dx = -K d
-            const float d = both_halves(fold(half16(Hc, xL, at_times(zero2)))) + gc;
+            const T d = both_halves(fold(h_times(at_times(zero2)))) + gc;
             dL[c] = d;
-            const float dx = -both_halves(fold(half16(Kc, dL, zero2)));
+            const T dx = -both_halves(fold(k_times()));
             x += (double)dx;
             dxL[c] = dx;
-            xL[c] = (float)x;
+            xL[c] = (T)x;
         }
         {                                                               // row role: A x, z
             zt += (double)a_times();
@@ -191,9 +189,9 @@ __global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 wa
         if ((k % a.check_interval) == 0) {                              // :218 (Q3 fixed: always check)
             const int ri_before = ri;
             rho_est = residuals(rho_est, pri, dua);                     // :220 (Q4: estimate is carried)
-            if (rho_est > (float)a.rhos[ri] * tolT && ri < a.nrho - 1)            // :223
+            if (rho_est > (T)a.rhos[ri] * tolT && ri < a.nrho - 1)                // :223
                 ri += 1;
-            else if (rho_est < (float)a.rhos[ri] / tolT && ri > 0)                // :226
+            else if (rho_est < (T)a.rhos[ri] / tolT && ri > 0)                    // :226
                 ri -= 1;
             if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && lane == 0) {
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
@@ -201,10 +199,10 @@ __global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 wa
             }
             if (ri != ri_before) {                                      // "re-factor" = table lookup
                 load_K();
-                rv = (float)a.rhos[ri] * cr;
+                rv = (T)a.rhos[ri] * cr;
                 inv = 1.0 / (double)rv;
             }
-            if (pri < (float)a.thr_p && dua < (float)a.thr_d) {         // :233
+            if (pri < (T)a.thr_p && dua < (T)a.thr_d) {                 // :233
                 converged = true;
                 break;
             }
@@ -213,14 +211,14 @@ __global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 wa
     if (!converged) rho_est = residuals(rho_est, pri, dua);             // :243 (Q11 fixed: fresh state)
 
     // objective 1/2 x'Hx + g'x (compute_J :320-322): hx holds H x of the final state
-    double jp = (h == 0 && cok) ? (double)((float)x * (0.5f * hx + gc)) : 0.0;
+    double jp = (h == 0 && cok) ? (double)((T)x * ((T)0.5 * hx + gc)) : 0.0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
 
     // ---- update_results (:278-305) and the persistent state
-    if (a.out_x && h == 0 && cok) ((float*)a.out_x)[(size_t)b * n + c] = (float)x;
-    if (a.out_z && rok) ((float*)a.out_z)[(size_t)b * m + r] = (float)z;
-    if (a.out_lam && rok) ((float*)a.out_lam)[(size_t)b * m + r] = (float)lam;
+    if (a.out_x && h == 0 && cok) ((T*)a.out_x)[(size_t)b * n + c] = (T)x;
+    if (a.out_z && rok) ((T*)a.out_z)[(size_t)b * m + r] = (T)z;
+    if (a.out_lam && rok) ((T*)a.out_lam)[(size_t)b * m + r] = (T)lam;
     if (lane == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
@@ -238,9 +236,12 @@ __global__ void __launch_bounds__(64, 3) k_admm_wave(SolveArgs a) {      // 3 wa
     }
 }
 
-bool rqp_wave_fits(const rqp_handle* h) { return h->esz == 4 && h->n <= WNC && h->m <= WMC; }
+bool rqp_wave_fits(const rqp_handle* h) { return h->n <= WNC && h->m <= WMC; }
 
 hipError_t rqp_launch_solve_wave(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    k_admm_wave<<<h->B, 64, 0, s>>>(a);
+    if (h->esz == 4)
+        k_admm_wave<float><<<h->B, 64, 0, s>>>(a);
+    else
+        k_admm_wave<double><<<h->B, 64, 0, s>>>(a);
     return hipGetLastError();
 }

@@ -42,8 +42,11 @@ def _model(H, g, A, l, u, precision=torch.float64, generic=False, wave=True, **k
     finally:
         os.environ["RQP_FORCE_GENERIC"] = "0"
         os.environ.pop("RQP_WAVE", None)
-    if generic or precision == torch.float64:
+    if generic:
         assert m.kernel == "generic"
+    elif precision == torch.float64:            # float64: the one-wavefront kernel for small problems, else streaming
+        small = H.shape[-1] <= 32 and A.shape[-2] <= 64
+        assert m.kernel == ("wave" if (small and wave) else "generic")
     return m
 
 
@@ -314,6 +317,30 @@ def test_resident_equals_generic_fp32():
     np.testing.assert_allclose(_np(rr.x)[~same], _np(rg.x)[~same], rtol=0, atol=1e-2 * scale)   # eps_abs-level agreement
     assert all(s == "solved" for s in rg.info.status)
     assert all(s == "solved" for s in rr.info.status)
+
+
+@pytest.mark.parametrize("prec,tol", [(torch.float64, 1e-10), (torch.float32, 5e-5)])
+def test_wave_equals_generic_small_problems(prec, tol):
+    """The one-wavefront kernel and the streaming kernel run the same recurrence in the same precision: identical
+    iteration counts and exits; x, z, lam agree to rounding (float64) / float32 noise.  (Keeps the streaming kernel
+    covered at small sizes, where the default dispatch no longer uses it.)"""
+    B, n, n_eq, n_ineq = 40, 24, 6, 42
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=700, feasible=True)
+    mw = _model(H, g, A, l, u, precision=prec)
+    mg = _model(H, g, A, l, u, precision=prec, generic=True)
+    assert mw.kernel == "wave" and mg.kernel == "generic"
+    rw, rg = mw.solve(), mg.solve()
+    itw, itg = rw.info.iter.cpu().numpy(), rg.info.iter.cpu().numpy()
+    assert rw.info.status == rg.info.status and all(s == "solved" for s in rg.info.status)
+    if prec == torch.float64:
+        assert np.array_equal(itw, itg)
+    assert np.mean(itw == itg) >= 0.9
+    same = itw == itg
+    scale = float(rg.x.abs().max())
+    for a_, b_, w in ((rw.x, rg.x, 1.0), (rw.z, rg.z, 1.0), (rw.y, rg.y, 40.0)):      # duals carry rho-amplified float32 noise
+        np.testing.assert_allclose(_np(a_)[same], _np(b_)[same], rtol=0, atol=w * tol * max(1.0, float(b_.abs().max()), scale))
+    np.testing.assert_allclose(_np(rw.info.obj_val)[same], _np(rg.info.obj_val)[same], rtol=max(tol, 1e-9) * 10, atol=tol * 10)
+    assert np.array_equal(rw.info.rho_ind.cpu().numpy()[same], rg.info.rho_ind.cpu().numpy()[same])
 
 
 @pytest.mark.parametrize("n,n_eq,n_ineq,kernel", [
