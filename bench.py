@@ -116,7 +116,7 @@ def main():
     from reluqp import distributed as D
     rank, world, local_rank, dist = D.init()          # nccl (= RCCL) when WORLD_SIZE > 1; barrier/reductions only
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)
     torch.cuda.set_device(dev)
 
     import reluqp.reluqpth as reluqpth

@@ -28,6 +28,13 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def local_device(local_rank):
+    """The GPU of this rank: LOCAL_RANK, folded into the visible device count (a launcher that narrows
+    HIP_VISIBLE_DEVICES to one GPU per process leaves every rank with device 0)."""
+    nd = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % nd if nd > 0 else 0)
+
+
 def init(backend=None):
     """Join the process group when WORLD_SIZE > 1.  Returns (rank, world, local_rank, dist|None)."""
     rank, world, local_rank = env_rank()
@@ -35,12 +42,13 @@ def init(backend=None):
         return rank, world, local_rank, None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:      # RQP_DIST_BACKEND=gloo: rehearse several ranks on ONE GPU (RCCL refuses two ranks per device)
+        backend = os.environ.get("RQP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+            dev = local_device(local_rank)
+            torch.cuda.set_device(dev)
+            dist.init_process_group(backend, device_id=dev)
         else:
             dist.init_process_group(backend)
     return rank, world, local_rank, dist
@@ -49,6 +57,8 @@ def init(backend=None):
 def reduce_report(dist, device, elapsed_s, sum_iters, n_solved, n_qps, extra_max=()):
     """Whole-job numbers: MAX over ranks of the times, SUM over ranks of the counts.
     Returns (elapsed_max, [extra maxima...], total_iters, total_solved, total_qps)."""
+    if dist is not None and dist.get_backend() == "gloo":
+        device = "cpu"
     tmax = torch.tensor([elapsed_s] + list(extra_max), dtype=torch.float64, device=device)
     tsum = torch.tensor([float(sum_iters), float(n_solved), float(n_qps)], dtype=torch.float64, device=device)
     if dist is not None:
