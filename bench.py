@@ -95,20 +95,30 @@ def pmc_traffic(kernel, args, kern_s):
     """HBM traffic of the dominant kernel in GB/s from the PMC passes committed under profiles/ (counters cannot be
     read from inside this process; the passes are separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
     this same command).  KB units, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md).  None when no profile of this
-    kernel on the default workload is committed."""
-    name = {"resident2": "r1_resident2/pmc_admm_res2.json", "resident": "r1_resident/pmc_admm_resident.json",
-            "generic": "r1_generic/pmc_admm_generic.json"}.get(kernel)
-    default_wl = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision) == ("random_qp", 4096, 100, 25, 275, "f32")
-    if name is None or not default_wl:
+    kernel on this workload is committed."""
+    sig = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision)
+    table = {
+        ("resident2", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_resident2/pmc_admm_res2.json",
+        ("resident", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_resident/pmc_admm_resident.json",
+        ("generic", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_generic/pmc_admm_generic.json",
+        ("wave", ("random_qp", 65536, 32, 8, 56, "f32")): "r1_wave/pmc_hbm.json",
+    }
+    name = table.get((kernel, sig))
+    if name is None and kernel == "mfma" and args.workload == "mpc" and args.batch == 4096 and args.precision == "f32":
+        name = "r1_mfma/pmc_hbm_b4096.json"
+    if name is None:
         return None, None
     path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
             pm = json.load(f)
-        kb = 2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])
+        if "hbm_bytes_per_launch" in pm:
+            nbytes = float(pm["hbm_bytes_per_launch"])
+        else:
+            nbytes = (2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])) * 1024.0
     except (OSError, KeyError, ValueError):
         return None, None
-    return kb * 1024.0 / kern_s / 1e9, "profiles/" + name + " (bytes per launch / this run's kernel time)"
+    return nbytes / kern_s / 1e9, "profiles/" + name + " (bytes per launch / this run's kernel time)"
 
 
 def main():
@@ -220,7 +230,8 @@ def main():
             # algorithmic flops 2*(2mn + 2n^2) per instance-iteration ("k_admm_mfma")
             tf = sum_iters * f_iter / kern_avg_s / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "GB/s (HBM)",
+                               "traffic_source": traffic_src,
                                "kernel": "k_admm_mfma", "kernel_ms": kern_avg_s * 1e3,
                                "algorithmic_flops_per_launch": sum_iters * f_iter}
         if world == 1 and args.cpu_seconds > 0:
