@@ -68,7 +68,11 @@ def main():
             N -= 1
         B = int(rs.choice([5, 16, 100, 700]))
         Ad, Bd = mpc.random_plant(nx, nu, seed=case)
-        ctl = mpc.LinearMPC(Ad, Bd, np.eye(nx), 0.1 * np.eye(nu), N, 0.5, 10.0, form="condensed")
+        try:
+            ctl = mpc.LinearMPC(Ad, Bd, np.eye(nx), 0.1 * np.eye(nu), N, 0.5, 10.0, form="condensed")
+        except Exception as e:          # the Riccati iteration of the generator gives up on some random plants (as upstream)
+            print("mfma    nx=%d nu=%d: plant skipped (%s)" % (nx, nu, e))
+            continue
         x0 = rs.randn(B, nx)
         g, l, u = ctl.qp_vectors(x0)
         mm, rm = solve(ctl.H, g, ctl.A, l, u, torch.float32, {"RQP_MFMA": "1"}, eps_abs=1e-3)
