@@ -232,8 +232,12 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     // (crossover measured on the condensed-MPC shape: 1024 -> resident 1.7x faster, 2048 -> even cold / MFMA 1.3x closed loop,
     //  3072 -> MFMA 1.35x / 1.8x)
     const char* mf = getenv("RQP_MFMA");                  // "0": never, "1": whenever it fits
+    // default: from ~2k instances (below, the per-instance kernels still win) and only for problems beyond the small /
+    // mid per-instance tiles -- the MFMA tile costs the same whatever the problem size (minus skipped zero groups), and
+    // on n=30, m=60 the one-wavefront kernel is 3-4x faster, on n=20, m=80 the mid resident tile is on par (measured)
+    const bool mfma_pays = h->B >= 2048 && (h->n > 56 || h->m > 128);
     h->use_mfma = rqp_mfma_fits(h) && !(force && force[0] == '1') && !(mf && mf[0] == '0') &&
-                  (h->B >= 2048 || (mf && mf[0] == '1'));      // below ~2k instances the per-instance kernel still wins (measured)
+                  (mfma_pays || (mf && mf[0] == '1'));
     if (h->use_mfma) {
         HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
         HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));

@@ -163,7 +163,7 @@ def test_mfma_persistent_grid_refills_slots():
     B = 256 * 16 * 2 + 16 * 3 + 5
     ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=9, B=B)
     g, l, u = ctl.qp_vectors(x0)
-    mm, rm = _solve_with_env(None, ctl, g, l, u, eps_abs=1e-3)
+    mm, rm = _solve_with_env("1", ctl, g, l, u, eps_abs=1e-3)      # (forced: at n=20, m=80 the default stays per-instance)
     mr, rr = _solve_with_env("0", ctl, g, l, u, eps_abs=1e-3)
     assert mm.kernel == "mfma" and mr.kernel.startswith("resident")
     assert rm.info.status == rr.info.status
