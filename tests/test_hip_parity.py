@@ -474,3 +474,44 @@ def test_c2_full_size_properties():
     it2 = r2.info.iter.cpu().numpy()
     assert all(s == "solved" for s in r2.info.status)
     assert np.median(it2) == 25 and it2.mean() < 0.5 * it.mean()
+
+
+def test_cabi_error_paths_on_device():
+    """Negative return codes of the C ABI with a live handle: call order, NULL / out-of-range arguments."""
+    import ctypes
+    from reluqp import _cabi
+    lib = _cabi.load()
+    dev = _dev()
+    s = _cabi.CSettings()
+    lib.rqp_default_settings(ctypes.byref(s))
+    d = _cabi.Dims(n=4, m=6, batch=2, shared_mats=0, dtype=0, reserved=0)
+    h = ctypes.c_void_p()
+    assert lib.rqp_create(ctypes.byref(h), ctypes.byref(d), ctypes.byref(s), dev.index or 0) == 0
+    try:
+        x = torch.zeros(2, 4, device=dev)
+        z = torch.zeros(2, 6, device=dev)
+        info = _cabi.CInfo()
+        assert lib.rqp_solve(h, _cabi.ptr(x), _cabi.ptr(z), None, ctypes.byref(info), None) == -2      # not set up
+        assert lib.rqp_update(h, _cabi.ptr(x), None, None, None) == -2
+        H = torch.eye(4, device=dev).repeat(2, 1, 1).contiguous()
+        A = torch.randn(2, 6, 4, device=dev)
+        g = torch.randn(2, 4, device=dev)
+        lo, up = -torch.ones(2, 6, device=dev), torch.ones(2, 6, device=dev)
+        assert lib.rqp_setup(h, _cabi.ptr(H), None, _cabi.ptr(A), _cabi.ptr(lo), _cabi.ptr(up), None) == -1   # NULL g
+        assert lib.rqp_setup(h, _cabi.ptr(H), _cabi.ptr(g), _cabi.ptr(A), _cabi.ptr(lo), _cabi.ptr(up), None) == 0
+        p = torch.randn(2, 3, device=dev)
+        G, LU = torch.randn(4, 3, device=dev), torch.randn(6, 3, device=dev)
+        l0, u0 = -torch.ones(6, device=dev), torch.ones(6, device=dev)
+        assert lib.rqp_update_affine(h, _cabi.ptr(p), 0, _cabi.ptr(G), _cabi.ptr(LU), _cabi.ptr(l0), _cabi.ptr(u0), None) == -1
+        assert lib.rqp_update_affine(h, _cabi.ptr(p), 65, _cabi.ptr(G), _cabi.ptr(LU), _cabi.ptr(l0), _cabi.ptr(u0), None) == -1
+        assert lib.rqp_update_affine(h, None, 3, _cabi.ptr(G), _cabi.ptr(LU), _cabi.ptr(l0), _cabi.ptr(u0), None) == -1
+        assert lib.rqp_update_affine(h, _cabi.ptr(p), 3, _cabi.ptr(G), _cabi.ptr(LU), _cabi.ptr(l0), _cabi.ptr(u0), None) == 0
+        assert lib.rqp_solve(h, _cabi.ptr(x), _cabi.ptr(z), None, ctypes.byref(info), None) == 0
+        torch.cuda.synchronize()
+        bad = _cabi.CSettings()
+        lib.rqp_default_settings(ctypes.byref(bad))
+        bad.rho = 0.7                                             # not changeable after setup (reluqpth.py:185-199)
+        assert lib.rqp_update_settings(h, ctypes.byref(bad)) == -1
+        assert b"" != lib.rqp_last_error(h)
+    finally:
+        lib.rqp_destroy(h)
