@@ -190,24 +190,29 @@ class LinearMPC(object):
             sol = sol[None]
         return self.first_input(sol, x), res
 
+    def _device_maps(self, device, dtype):
+        """Constant maps of the closed loop on the device.  With u0 = v0 - K x the plant step is
+        x+ = Ad x + Bd u0 = (Ad - Bd K) x + Bd v0: two GEMMs per step (Acl' and Bd' are what they multiply from the right)."""
+        import torch
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dtype)
+        return dict(gmap=t(self.g_x0), lumap=t(self.lu_x0), ladd=t(self.l_add), uadd=t(self.u_add),
+                    Aclt=t((self.Ad - self.Bd @ self.K).T), Bdt=t(self.Bd.T))
+
     def simulate_device(self, x0, steps, device, dtype):
         """Closed loop with every per-step map on the device (no host round trip per control step):
-        g = x g_x0', l/u = l_add/u_add + x lu_x0', update + warm solve, u0 = v0 - x K', x+ = x Ad' + u0 Bd'.
-        torch is used here for the caller-side data maps only; the QP solve is the HIP path.
+        g = G x, l/u = l_add/u_add + LU x (rqp_update_affine), warm solve, x+ = (Ad - Bd K) x + Bd v0 with v0 the first
+        input block of the solution.  torch is used here for the caller-side plant step only; the QP path is the HIP library.
         Returns (final states [B, nx] tensor, mean ADMM iterations per solve)."""
         import torch
         assert self.form == "condensed"
-        t = lambda a: torch.as_tensor(a, device=device, dtype=dtype)
-        gx, lux, ladd, uadd = t(self.g_x0.T), t(self.lu_x0.T), t(self.l_add), t(self.u_add)
-        Kt, Adt, Bdt = t(self.K.T), t(self.Ad.T), t(self.Bd.T)
-        x = t(np.atleast_2d(x0))
-        it_sum = torch.zeros((), device=device, dtype=torch.float64)
-        fresh = False
-        gmap, lumap = gx.T.contiguous(), lux.T.contiguous()       # [n, nx], [m, nx]
+        mp = self._device_maps(device, dtype)
+        x = torch.as_tensor(np.atleast_2d(x0), device=device, dtype=dtype)
+        it_acc = None
         for k in range(steps):
+            fresh = False
             if not self._ready:
-                shift = x @ lux
-                g, l, u = x @ gx, ladd + shift, uadd + shift
+                shift = x @ mp["lumap"].T
+                g, l, u = x @ mp["gmap"].T, mp["ladd"] + shift, mp["uadd"] + shift
                 import reluqp.reluqpth as reluqpth
                 self.solver = self.solver or reluqpth.ReLU_QP()
                 self.solver.setup(self.H, g, self.A, l, u, **self.solver_kw)
@@ -216,17 +221,14 @@ class LinearMPC(object):
             sync = self.solver.synchronous
             self.solver.synchronous = False          # enqueue only: the steps chain on the stream, no host wait per step
             try:
-                if fresh:
-                    fresh = False
-                else:                                # g = G x, l/u = l_add/u_add + LU x in one device pass
-                    self.solver.update_affine(x, gmap, lumap, ladd, uadd)
+                if not fresh:                        # g = G x, l/u = l_add/u_add + LU x in one device pass
+                    self.solver.update_affine(x, mp["gmap"], mp["lumap"], mp["ladd"], mp["uadd"])
                 res = self.solver.solve()
             finally:
                 self.solver.synchronous = sync
-            u0 = res.x[:, :self.nu] - x @ Kt
-            x = x @ Adt + u0 @ Bdt
-            it_sum += res.info.iter.sum()
-        return x, float(it_sum) / (steps * x.shape[0])
+            x = torch.addmm(x @ mp["Aclt"], res.x[:, :self.nu], mp["Bdt"])
+            it_acc = res.info.iter.clone() if it_acc is None else it_acc.add_(res.info.iter)
+        return x, float(it_acc.sum()) / (steps * x.shape[0])
 
     def simulate_graph(self, x0, steps, device, dtype):
         """simulate_device with the control step (x0 update, warm-started solve, plant step) captured ONCE in a HIP graph
@@ -234,20 +236,17 @@ class LinearMPC(object):
         The solver must be set up (run simulate_device for one step first).  Returns as simulate_device."""
         import torch
         assert self.form == "condensed" and self._ready
-        t = lambda a: torch.as_tensor(a, device=device, dtype=dtype)
-        gmap, lumap, ladd, uadd = t(self.g_x0).contiguous(), t(self.lu_x0).contiguous(), t(self.l_add), t(self.u_add)
-        Kt, Adt, Bdt = t(self.K.T), t(self.Ad.T), t(self.Bd.T)
-        x = t(np.atleast_2d(x0)).clone()                      # static buffer: the graph reads and rewrites it in place
-        it_sum = torch.zeros((), device=device, dtype=torch.float64)
+        mp = self._device_maps(device, dtype)
+        x = torch.as_tensor(np.atleast_2d(x0), device=device, dtype=dtype).clone()   # static buffer: rewritten in place
+        it_acc = torch.zeros(x.shape[0], device=device, dtype=torch.int32)
         sync = self.solver.synchronous
         self.solver.synchronous = False
         try:
             def step():
-                self.solver.update_affine(x, gmap, lumap, ladd, uadd)
+                self.solver.update_affine(x, mp["gmap"], mp["lumap"], mp["ladd"], mp["uadd"])
                 res = self.solver.solve()
-                u0 = res.x[:, :self.nu] - x @ Kt
-                x.copy_(x @ Adt + u0 @ Bdt)
-                it_sum.add_(res.info.iter.sum())
+                x.copy_(torch.addmm(x @ mp["Aclt"], res.x[:, :self.nu], mp["Bdt"]))
+                it_acc.add_(res.info.iter)
             side = torch.cuda.Stream(device=device)           # warm-up on a side stream, as torch's capture rules ask
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
@@ -262,7 +261,7 @@ class LinearMPC(object):
         finally:
             self.solver.synchronous = sync
         torch.cuda.synchronize(device)
-        return x, float(it_sum) / (max(steps, done) * x.shape[0])
+        return x, float(it_acc.sum()) / (max(steps, done) * x.shape[0])
 
     def simulate(self, x0, steps, noise=0.0, seed=0):
         """Closed loop x+ = Ad x + Bd u (+ noise); returns (states [steps+1, B, nx], inputs, iteration counts)."""
