@@ -123,6 +123,12 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
         return acc[0] + acc[1];
     };
     auto fold = [&](pair v) __attribute__((always_inline)) { return v[0] + v[1]; };
+    // lanes hand vectors to each other through LDS inside the wave: a wavefront-scope release + wave barrier orders the
+    // hand-off for the compiler (the hardware already executes a wave's LDS operations in order)
+    auto handoff = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     auto both_halves = [&](T v) __attribute__((always_inline)) { return v + (T)__shfl_xor(v, 32, 64); };
 
     // (by-column LDS vectors are written by BOTH halves of a column -- same value, same address: no exec-masked region
@@ -131,6 +137,7 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
     // A x of the incoming state
     dxL[c] = (T)x;
     xL[c] = (T)x;
+    handoff();
     double zt = (double)a_times();
 
     bool converged = false;
@@ -143,6 +150,7 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
     // compute_residuals (:307-318) on the current state; leaves H x of the column in hx
     auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
         nuL[r] = (T)lam;
+        handoff();
         const T t3 = both_halves(fold(at_times(zero2)));                // A' lam
         hx = both_halves(fold(h_times(zero2)));                         // H x
         const T v0 = wave_tmax((T)fabs((T)(zt - z)));
@@ -169,14 +177,17 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
             lam = lh;
             nuL[r] = (T)(lh + (double)rv * p);
         }
+        handoff();
         {                                                               // column role: d = H x + g + A' nu ; dx = -K d
             const T d = both_halves(fold(h_times(at_times(zero2)))) + gc;
             dL[c] = d;
+            handoff();
             const T dx = -both_halves(fold(k_times()));
             x += (double)dx;
             dxL[c] = dx;
             xL[c] = (T)x;
         }
+        handoff();
         {                                                               // row role: A x, z
             zt += (double)a_times();
             const double v = zt + lam * inv;
