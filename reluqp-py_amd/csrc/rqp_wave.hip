@@ -1,23 +1,23 @@
-// rqp_wave.hip -- ADMM hot loop for SMALL per-instance problems (n <= 32, m <= 64; BASELINE config 4 shape):
-// ONE WAVEFRONT = ONE QP.  A 256-thread workgroup per instance is latency- and barrier-bound at this size (3072 MACs
-// per iteration); here the whole solve of an instance runs inside one wave with every matrix in its registers, no
-// barrier at all (LDS operations of a wave execute in order), and the CU keeps many instances in flight.
+// rqp_wave.hip -- ADMM hot loop for SMALL per-instance problems: ONE WAVEFRONT = ONE QP.
+//   k_admm_wave<T, 32, 64>       n <= 32, m <= 64    (BASELINE config 4 shape), float and double
+//   k_admm_wave<float, 32, 128>  n <= 32, m <= 128   (two rows per lane: short-horizon condensed MPC, m = N (nx + nu) > 64)
+// A 256-thread workgroup per instance is latency- and barrier-bound at these sizes (3072 MACs per iteration at n=32,
+// m=64); here the whole solve of an instance runs inside one wave with every matrix in its registers, no barrier at all
+// (LDS operations of a wave execute in order), and the CU keeps several instances in flight.
 //
-// Lane l plays two roles:
-//   row role     r = l            (constraint row):  Ar[c] = A[r][c], the float64 row state z, lam, A x, and l, u, rho
-//   column role  c = l & 31, h = l >> 5:  half h of column c:  Atc[j] = A[32 h + j][c],  Kc[j] = K[c][16 h + j],
-//                                         Hc[j] = H[c][16 h + j];  x[c] (float64) and g[c] are kept by both halves
-// so A is held twice (row-major for A dx, column-major for A' nu): 32 + 32 + 16 + 16 = 96 VGPRs of matrices.
-// Vectors cross between the roles through 640 B of LDS read with wave-uniform-per-half addresses (broadcast reads,
-// ds_read_b128); the two halves of a column meet with one cross-half shuffle.
+// Lane l plays two roles (NC = column cap, MC = row cap, HALF = 64 / NC lanes per column, RL = MC / 64 rows per lane):
+//   row role     rows r_q = l + 64 q, q < RL:  Ar[q][:] = A[r_q][:], the float64 row state z, lam, A x, and l, u, rho
+//   column role  c = l % NC, h = l / NC:  part h of column c:  Atc[j] = A[(MC/HALF) h + j][c],
+//                Kc[j] = K[c][(NC/HALF) h + j],  Hc[j] = H[c][(NC/HALF) h + j];  x[c] (float64) and g[c] on every part
+// so A is held twice (row-major for A dx, column-major for A' nu).  Vectors cross between the roles through LDS read with
+// wave-uniform-per-part addresses (broadcast ds_read_b128); with HALF = 2 the two parts of a column meet with one
+// cross-half shuffle.
 // Same recurrence (oracle/reluqp_oracle.py: forward_refine), check logic and quirk dispositions as k_admm_generic
 // (rqp_admm.hip; reference line citations there); products in T (float: packed FMAs; double: the reference's default
 // precision, same layout with twice the registers), float64 state.
 #include "rqp_common.h"
 
 namespace {
-
-constexpr int WNC = 32, WMC = 64;      // caps: n <= 32, m <= 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -30,13 +30,20 @@ template <>
 struct WV<float> {
     typedef f32x4 chunk;
     typedef f32x2 pair;
-    static constexpr int W = 4, OCC = 3;      // elements per chunk; waves per SIMD (<= 168 VGPRs)
+    static constexpr int W = 4;               // elements per chunk
 };
 template <>
 struct WV<double> {
     typedef f64x2 chunk;
     typedef f64x2 pair;
-    static constexpr int W = 2, OCC = 1;      // matrices alone are 192 VGPRs
+    static constexpr int W = 2;
+};
+
+// waves per SIMD the register budget allows (matrix registers: A by row + A by column + K + H)
+template <typename T, int NC, int MC>
+struct WOcc {
+    static constexpr int regs = (int)(sizeof(T) / 4) * (NC * (MC / 64) + MC / (64 / NC) + 2 * NC / (64 / NC));
+    static constexpr int value = regs <= 96 ? 3 : (regs <= 160 ? 2 : 1);   // VALU operands must sit in the 256 arch VGPRs
 };
 
 template <typename T>
@@ -52,19 +59,22 @@ __device__ __forceinline__ T wave_tmax(T v) {
 
 }   // namespace
 
-template <typename T>
-__global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
+template <typename T, int NC, int MC>
+__global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(SolveArgs a) {
     typedef typename WV<T>::chunk chunk;
     typedef typename WV<T>::pair pair;
     constexpr int W = WV<T>::W, PW = W / 2;                            // elements / pairs per 16-byte chunk
-    __shared__ __attribute__((aligned(16))) T nuL[WMC];                // nu (lam at a check) by row
-    __shared__ __attribute__((aligned(16))) T xL[WNC];                 // x by column
-    __shared__ __attribute__((aligned(16))) T dL[WNC];                 // d by column
-    __shared__ __attribute__((aligned(16))) T dxL[WNC];                // dx by column
+    constexpr int HALF = 64 / NC, RL = MC / 64;                        // lanes per column; rows per lane
+    constexpr int AT = MC / HALF, KH = NC / HALF;                      // rows of A / columns of K, H per column part
+    static_assert(NC * HALF == 64 && RL * 64 == MC && (HALF == 1 || HALF == 2), "lane mapping");
+    __shared__ __attribute__((aligned(16))) T nuL[MC];                 // nu (lam at a check) by row
+    __shared__ __attribute__((aligned(16))) T xL[NC];                  // x by column
+    __shared__ __attribute__((aligned(16))) T dL[NC];                  // d by column
+    __shared__ __attribute__((aligned(16))) T dxL[NC];                 // dx by column
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
-    const int r = lane, c = lane & 31, h = lane >> 5;
-    const bool rok = r < m, cok = c < n;
+    const int c = lane % NC, h = lane / NC;
+    const bool cok = c < n;
     const T* A = (const T*)a.A + (size_t)b * a.sA;
     const T* At = (const T*)a.At + (size_t)b * a.sAt;
     const T* Ht = (const T*)a.Ht + (size_t)b * a.sH;
@@ -72,7 +82,7 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
 
     // ---- matrices into registers (leading dimensions are multiples of 16 bytes, padding is zero); kept as element pairs:
     //      every product runs on pair FMAs (v_pk_fma_f32 for float) -- two accumulators, even / odd elements, added at the end
-    pair Ar[WNC / 2], Atc[16], Hc[8], Kc[8];
+    pair Ar[RL][NC / 2], Atc[AT / 2], Hc[KH / 2], Kc[KH / 2];
     auto load_row = [&](pair* dst, int len, const T* src, bool ok, int ld_left) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < len / W; ++q) {
@@ -84,25 +94,33 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
             for (int e = 0; e < PW; ++e) dst[q * PW + e] = (pair){v[2 * e], v[2 * e + 1]};
         }
     };
-    load_row(Ar, WNC, A + (size_t)r * ldn, rok, ldn);                        // row r of A
-    load_row(Atc, 32, At + (size_t)c * ldm + 32 * h, cok, ldm - 32 * h);     // rows 32 h .. of column c
-    load_row(Hc, 16, Ht + (size_t)c * ldn + 16 * h, cok, ldn - 16 * h);      // sym(H): row c = column c
+#pragma unroll
+    for (int q = 0; q < RL; ++q) load_row(Ar[q], NC, A + (size_t)(lane + 64 * q) * ldn, lane + 64 * q < m, ldn);   // row r_q of A
+    load_row(Atc, AT, At + (size_t)c * ldm + AT * h, cok, ldm - AT * h);     // rows AT h .. of column c
+    load_row(Hc, KH, Ht + (size_t)c * ldn + KH * h, cok, ldn - KH * h);      // sym(H): row c = column c
     int ri = a.rho_ind[b];
     auto load_K = [&]() __attribute__((always_inline)) {
-        load_row(Kc, 16, Kb + ((size_t)ri * n + c) * ldn + 16 * h, cok, ldn - 16 * h);
+        load_row(Kc, KH, Kb + ((size_t)ri * n + c) * ldn + KH * h, cok, ldn - KH * h);
     };
     load_K();
 
     // ---- vectors and state
     const T gc = cok ? ((const T*)a.g)[(size_t)b * n + c] : (T)0;
-    const T lr = rok ? ((const T*)a.l)[(size_t)b * m + r] : (T)0;
-    const T ur = rok ? ((const T*)a.u)[(size_t)b * m + r] : (T)0;
-    const T cr = rok ? ((const T*)a.c)[(size_t)b * m + r] : (T)1;
     double x = cok ? a.x[(size_t)b * n + c] : 0.0;
-    double z = rok ? a.z[(size_t)b * m + r] : 0.0;
-    double lam = rok ? a.lam[(size_t)b * m + r] : 0.0;
-    T rv = (T)a.rhos[ri] * cr;
-    double inv = 1.0 / (double)rv;
+    T lr[RL], ur[RL], cr[RL], rv[RL];
+    double z[RL], lam[RL], zt[RL], inv[RL];
+#pragma unroll
+    for (int q = 0; q < RL; ++q) {
+        const int r = lane + 64 * q;
+        const bool rok = r < m;
+        lr[q] = rok ? ((const T*)a.l)[(size_t)b * m + r] : (T)0;
+        ur[q] = rok ? ((const T*)a.u)[(size_t)b * m + r] : (T)0;
+        cr[q] = rok ? ((const T*)a.c)[(size_t)b * m + r] : (T)1;
+        z[q] = rok ? a.z[(size_t)b * m + r] : 0.0;
+        lam[q] = rok ? a.lam[(size_t)b * m + r] : 0.0;
+        rv[q] = (T)a.rhos[ri] * cr[q];
+        inv[q] = 1.0 / (double)rv[q];
+    }
 
     // products: column role reads by-row vectors (nuL) / by-column vectors (xL, dL); row role reads dxL
     auto dot = [&](const pair* M, int len, const T* vec, pair acc) __attribute__((always_inline)) {   // acc + sum M[j] vec[j], pairwise
@@ -115,11 +133,11 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
         return acc;
     };
     const pair zero2 = {(T)0, (T)0};
-    auto at_times = [&](pair acc) __attribute__((always_inline)) { return dot(Atc, 32, nuL + 32 * h, acc); };   // + A[32 h..][c]' nu[32 h..]
-    auto h_times = [&](pair acc) __attribute__((always_inline)) { return dot(Hc, 16, xL + 16 * h, acc); };     // + H[c][16 h..] x[16 h..]
-    auto k_times = [&]() __attribute__((always_inline)) { return dot(Kc, 16, dL + 16 * h, zero2); };           // K[c][16 h..] d[16 h..]
-    auto a_times = [&]() __attribute__((always_inline)) {                                                      // A[r][:] dx
-        const pair acc = dot(Ar, WNC, dxL, zero2);
+    auto at_times = [&](pair acc) __attribute__((always_inline)) { return dot(Atc, AT, nuL + AT * h, acc); };   // + A[AT h..][c]' nu[AT h..]
+    auto h_times = [&](pair acc) __attribute__((always_inline)) { return dot(Hc, KH, xL + KH * h, acc); };     // + H[c][KH h..] x[KH h..]
+    auto k_times = [&]() __attribute__((always_inline)) { return dot(Kc, KH, dL + KH * h, zero2); };           // K[c][KH h..] d[KH h..]
+    auto a_times = [&](int q) __attribute__((always_inline)) {                                                 // A[r_q][:] dx
+        const pair acc = dot(Ar[q], NC, dxL, zero2);
         return acc[0] + acc[1];
     };
     auto fold = [&](pair v) __attribute__((always_inline)) { return v[0] + v[1]; };
@@ -129,16 +147,20 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto both_halves = [&](T v) __attribute__((always_inline)) { return v + (T)__shfl_xor(v, 32, 64); };
+    auto all_parts = [&](T v) __attribute__((always_inline)) {          // sum over the HALF parts of a column
+        if constexpr (HALF == 2) v += (T)__shfl_xor(v, 32, 64);
+        return v;
+    };
 
-    // (by-column LDS vectors are written by BOTH halves of a column -- same value, same address: no exec-masked region
+    // (by-column LDS vectors are written by EVERY part of a column -- same value, same address: no exec-masked region
     //  in the loop.  With the writes under `if (h == 0)` hipcc 7.2 moved the following full-wave ds_reads of the same
     //  array into the masked block, leaving lanes 32..63 with stale registers.)
     // A x of the incoming state
     dxL[c] = (T)x;
     xL[c] = (T)x;
     handoff();
-    double zt = (double)a_times();
+#pragma unroll
+    for (int q = 0; q < RL; ++q) zt[q] = (double)a_times(q);
 
     bool converged = false;
     int iters = 0;
@@ -149,13 +171,20 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
 
     // compute_residuals (:307-318) on the current state; leaves H x of the column in hx
     auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
-        nuL[r] = (T)lam;
+        T w0 = (T)0, w1 = (T)0, w2 = (T)0;
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {
+            nuL[lane + 64 * q] = (T)lam[q];
+            w0 = wtmax(w0, (T)fabs((T)(zt[q] - z[q])));
+            w1 = wtmax(w1, (T)fabs((T)zt[q]));
+            w2 = wtmax(w2, (T)fabs((T)z[q]));
+        }
         handoff();
-        const T t3 = both_halves(fold(at_times(zero2)));                // A' lam
-        hx = both_halves(fold(h_times(zero2)));                         // H x
-        const T v0 = wave_tmax((T)fabs((T)(zt - z)));
-        const T v1 = wave_tmax((T)fabs((T)zt));
-        const T v2 = wave_tmax((T)fabs((T)z));
+        const T t3 = all_parts(fold(at_times(zero2)));                  // A' lam
+        hx = all_parts(fold(h_times(zero2)));                           // H x
+        const T v0 = wave_tmax(w0);
+        const T v1 = wave_tmax(w1);
+        const T v2 = wave_tmax(w2);
         const T v3 = wave_tmax((T)fabs(hx + t3 + gc));
         const T v4 = wave_tmax((T)fabs(hx));
         const T v5 = wave_tmax((T)fabs(t3));
@@ -171,30 +200,32 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
     };
 
     for (int k = 1; k <= kmax; ++k) {
-        {                                                               // row role: lam_hat, nu
-            const double p = zt - z;
-            const double lh = lam + (double)rv * p;
-            lam = lh;
-            nuL[r] = (T)(lh + (double)rv * p);
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {                                  // row role: lam_hat, nu
+            const double p = zt[q] - z[q];
+            const double lh = lam[q] + (double)rv[q] * p;
+            lam[q] = lh;
+            nuL[lane + 64 * q] = (T)(lh + (double)rv[q] * p);
         }
         handoff();
         {                                                               // column role: d = H x + g + A' nu ; dx = -K d
-            const T d = both_halves(fold(h_times(at_times(zero2)))) + gc;
+            const T d = all_parts(fold(h_times(at_times(zero2)))) + gc;
             dL[c] = d;
             handoff();
-            const T dx = -both_halves(fold(k_times()));
+            const T dx = -all_parts(fold(k_times()));
             x += (double)dx;
             dxL[c] = dx;
             xL[c] = (T)x;
         }
         handoff();
-        {                                                               // row role: A x, z
-            zt += (double)a_times();
-            const double v = zt + lam * inv;
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {                                  // row role: A x, z
+            zt[q] += (double)a_times(q);
+            const double v = zt[q] + lam[q] * inv[q];
             double zn = v;                                              // torch.clamp: NaN stays NaN
-            if (v < (double)lr) zn = (double)lr;
-            if (v > (double)ur) zn = (double)ur;
-            z = zn;
+            if (v < (double)lr[q]) zn = (double)lr[q];
+            if (v > (double)ur[q]) zn = (double)ur[q];
+            z[q] = zn;
         }
         iters = k;
         if ((k % a.check_interval) == 0) {                              // :218 (Q3 fixed: always check)
@@ -210,8 +241,11 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
             }
             if (ri != ri_before) {                                      // "re-factor" = table lookup
                 load_K();
-                rv = (T)a.rhos[ri] * cr;
-                inv = 1.0 / (double)rv;
+#pragma unroll
+                for (int q = 0; q < RL; ++q) {
+                    rv[q] = (T)a.rhos[ri] * cr[q];
+                    inv[q] = 1.0 / (double)rv[q];
+                }
             }
             if (pri < (T)a.thr_p && dua < (T)a.thr_d) {                 // :233
                 converged = true;
@@ -228,8 +262,6 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
 
     // ---- update_results (:278-305) and the persistent state
     if (a.out_x && h == 0 && cok) ((T*)a.out_x)[(size_t)b * n + c] = (T)x;
-    if (a.out_z && rok) ((T*)a.out_z)[(size_t)b * m + r] = (T)z;
-    if (a.out_lam && rok) ((T*)a.out_lam)[(size_t)b * m + r] = (T)lam;
     if (lane == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
@@ -241,18 +273,34 @@ __global__ void __launch_bounds__(64, WV<T>::OCC) k_admm_wave(SolveArgs a) {
         a.rho_ind[b] = a.warm_starting ? ri : a.rho_ind0;
     }
     if (h == 0 && cok) a.x[(size_t)b * n + c] = a.warm_starting ? x : 0.0;           // state persists (:304) or is cleared (:324-333)
-    if (rok) {
-        a.z[(size_t)b * m + r] = a.warm_starting ? z : 0.0;
-        a.lam[(size_t)b * m + r] = a.warm_starting ? lam : 0.0;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) {
+        const int r = lane + 64 * q;
+        if (r < m) {
+            if (a.out_z) ((T*)a.out_z)[(size_t)b * m + r] = (T)z[q];
+            if (a.out_lam) ((T*)a.out_lam)[(size_t)b * m + r] = (T)lam[q];
+            a.z[(size_t)b * m + r] = a.warm_starting ? z[q] : 0.0;
+            a.lam[(size_t)b * m + r] = a.warm_starting ? lam[q] : 0.0;
+        }
     }
 }
 
-bool rqp_wave_fits(const rqp_handle* h) { return h->n <= WNC && h->m <= WMC; }
+// 0: does not fit; 1: <T, 32, 64>; 2: <float, 32, 128>
+static int wave_class(const rqp_handle* h) {
+    if (h->n <= 32 && h->m <= 64) return 1;
+    if (h->esz == 4 && h->n <= 32 && h->m <= 128) return 2;
+    return 0;
+}
+
+bool rqp_wave_fits(const rqp_handle* h) { return wave_class(h) != 0; }
 
 hipError_t rqp_launch_solve_wave(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    if (h->esz == 4)
-        k_admm_wave<float><<<h->B, 64, 0, s>>>(a);
+    const int wc = wave_class(h);
+    if (wc == 2)
+        k_admm_wave<float, 32, 128><<<h->B, 64, 0, s>>>(a);
+    else if (h->esz == 4)
+        k_admm_wave<float, 32, 64><<<h->B, 64, 0, s>>>(a);
     else
-        k_admm_wave<double><<<h->B, 64, 0, s>>>(a);
+        k_admm_wave<double, 32, 64><<<h->B, 64, 0, s>>>(a);
     return hipGetLastError();
 }
