@@ -1,14 +1,17 @@
 // rqp_wave.hip -- ADMM hot loop for SMALL per-instance problems: ONE WAVEFRONT = ONE QP.
 //   k_admm_wave<T, 32, 64>       n <= 32, m <= 64    (BASELINE config 4 shape), float and double
 //   k_admm_wave<float, 32, 128>  n <= 32, m <= 128   (two rows per lane: short-horizon condensed MPC, m = N (nx + nu) > 64)
+//   k_admm_wave<float, 32, 64, 2>  n <= 64, m <= 128  (TWO wavefronts per QP: each owns 32 columns and 64 rows; the three
+//                                  vector hand-offs of an iteration become workgroup barriers of a 128-thread workgroup)
 // A 256-thread workgroup per instance is latency- and barrier-bound at these sizes (3072 MACs per iteration at n=32,
 // m=64); here the whole solve of an instance runs inside one wave with every matrix in its registers, no barrier at all
 // (LDS operations of a wave execute in order), and the CU keeps several instances in flight.
 //
-// Lane l plays two roles (NC = column cap, MC = row cap, HALF = 64 / NC lanes per column, RL = MC / 64 rows per lane):
-//   row role     rows r_q = l + 64 q, q < RL:  Ar[q][:] = A[r_q][:], the float64 row state z, lam, A x, and l, u, rho
-//   column role  c = l % NC, h = l / NC:  part h of column c:  Atc[j] = A[(MC/HALF) h + j][c],
-//                Kc[j] = K[c][(NC/HALF) h + j],  Hc[j] = H[c][(NC/HALF) h + j];  x[c] (float64) and g[c] on every part
+// Lane l of wave w plays two roles (NC / MC = columns / rows per wave, NWV waves per QP: NCT = NC NWV columns and
+// MCT = MC NWV rows in all; HALF = 64 / NC lanes per column, RL = MC / 64 rows per lane):
+//   row role     rows r_q = MC w + l + 64 q, q < RL:  Ar[q][:] = A[r_q][:], the float64 row state z, lam, A x, and l, u, rho
+//   column role  c = NC w + l % NC, h = l / NC:  part h of column c:  Atc[j] = A[(MCT/HALF) h + j][c],
+//                Kc[j] = K[c][(NCT/HALF) h + j],  Hc[j] = H[c][(NCT/HALF) h + j];  x[c] (float64) and g[c] on every part
 // so A is held twice (row-major for A dx, column-major for A' nu).  Vectors cross between the roles through LDS read with
 // wave-uniform-per-part addresses (broadcast ds_read_b128); with HALF = 2 the two parts of a column meet with one
 // cross-half shuffle.
@@ -40,10 +43,12 @@ struct WV<double> {
 };
 
 // waves per SIMD the register budget allows (matrix registers: A by row + A by column + K + H)
-template <typename T, int NC, int MC>
+template <typename T, int NC, int MC, int NWV>
 struct WOcc {
-    static constexpr int regs = (int)(sizeof(T) / 4) * (NC * (MC / 64) + MC / (64 / NC) + 2 * NC / (64 / NC));
-    static constexpr int value = regs <= 96 ? 3 : (regs <= 160 ? 2 : 1);   // VALU operands must sit in the 256 arch VGPRs
+    static constexpr int regs = (int)(sizeof(T) / 4) * (NC * NWV * (MC / 64) + MC * NWV / (64 / NC) + 2 * NC * NWV / (64 / NC));
+    // waves per SIMD (VALU operands must sit in the 256 arch VGPRs); __launch_bounds__ counts workgroups of NWV waves
+    static constexpr int waves = regs <= 96 ? 3 : (regs <= 160 ? 2 : 1);
+    static constexpr int value = waves;
 };
 
 template <typename T>
@@ -59,21 +64,25 @@ __device__ __forceinline__ T wave_tmax(T v) {
 
 }   // namespace
 
-template <typename T, int NC, int MC>
-__global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(SolveArgs a) {
+template <typename T, int NC, int MC, int NWV = 1>
+__global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_admm_wave(SolveArgs a) {
     typedef typename WV<T>::chunk chunk;
     typedef typename WV<T>::pair pair;
     constexpr int W = WV<T>::W, PW = W / 2;                            // elements / pairs per 16-byte chunk
     constexpr int HALF = 64 / NC, RL = MC / 64;                        // lanes per column; rows per lane
-    constexpr int AT = MC / HALF, KH = NC / HALF;                      // rows of A / columns of K, H per column part
-    static_assert(NC * HALF == 64 && RL * 64 == MC && (HALF == 1 || HALF == 2), "lane mapping");
-    __shared__ __attribute__((aligned(16))) T nuL[MC];                 // nu (lam at a check) by row
-    __shared__ __attribute__((aligned(16))) T xL[NC];                  // x by column
-    __shared__ __attribute__((aligned(16))) T dL[NC];                  // d by column
-    __shared__ __attribute__((aligned(16))) T dxL[NC];                 // dx by column
-    const int b = blockIdx.x, lane = threadIdx.x;
+    constexpr int NCT = NC * NWV, MCT = MC * NWV;                      // columns / rows of the whole instance
+    constexpr int AT = MCT / HALF, KH = NCT / HALF;                    // rows of A / columns of K, H per column part
+    static_assert(NC * HALF == 64 && RL * 64 == MC && (HALF == 1 || HALF == 2) && (NWV == 1 || NWV == 2), "lane mapping");
+    __shared__ __attribute__((aligned(16))) T nuL[MCT];                // nu (lam at a check) by row
+    __shared__ __attribute__((aligned(16))) T xL[NCT];                 // x by column
+    __shared__ __attribute__((aligned(16))) T dL[NCT];                 // d by column
+    __shared__ __attribute__((aligned(16))) T dxL[NCT];                // dx by column
+    __shared__ T redL[NWV][8];                                         // cross-wave maxima / sums (NWV > 1)
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
-    const int c = lane % NC, h = lane / NC;
+    const int c = NC * wv + lane % NC, h = lane / NC;                  // global column, column part
+    const int r0 = MC * wv + lane;                                     // first row of this lane
     const bool cok = c < n;
     const T* A = (const T*)a.A + (size_t)b * a.sA;
     const T* At = (const T*)a.At + (size_t)b * a.sAt;
@@ -82,7 +91,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
 
     // ---- matrices into registers (leading dimensions are multiples of 16 bytes, padding is zero); kept as element pairs:
     //      every product runs on pair FMAs (v_pk_fma_f32 for float) -- two accumulators, even / odd elements, added at the end
-    pair Ar[RL][NC / 2], Atc[AT / 2], Hc[KH / 2], Kc[KH / 2];
+    pair Ar[RL][NCT / 2], Atc[AT / 2], Hc[KH / 2], Kc[KH / 2];
     auto load_row = [&](pair* dst, int len, const T* src, bool ok, int ld_left) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < len / W; ++q) {
@@ -95,7 +104,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
         }
     };
 #pragma unroll
-    for (int q = 0; q < RL; ++q) load_row(Ar[q], NC, A + (size_t)(lane + 64 * q) * ldn, lane + 64 * q < m, ldn);   // row r_q of A
+    for (int q = 0; q < RL; ++q) load_row(Ar[q], NCT, A + (size_t)(r0 + 64 * q) * ldn, r0 + 64 * q < m, ldn);   // row r_q of A
     load_row(Atc, AT, At + (size_t)c * ldm + AT * h, cok, ldm - AT * h);     // rows AT h .. of column c
     load_row(Hc, KH, Ht + (size_t)c * ldn + KH * h, cok, ldn - KH * h);      // sym(H): row c = column c
     int ri = a.rho_ind[b];
@@ -111,7 +120,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
     double z[RL], lam[RL], zt[RL], inv[RL];
 #pragma unroll
     for (int q = 0; q < RL; ++q) {
-        const int r = lane + 64 * q;
+        const int r = r0 + 64 * q;
         const bool rok = r < m;
         lr[q] = rok ? ((const T*)a.l)[(size_t)b * m + r] : (T)0;
         ur[q] = rok ? ((const T*)a.u)[(size_t)b * m + r] : (T)0;
@@ -137,15 +146,29 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
     auto h_times = [&](pair acc) __attribute__((always_inline)) { return dot(Hc, KH, xL + KH * h, acc); };     // + H[c][KH h..] x[KH h..]
     auto k_times = [&]() __attribute__((always_inline)) { return dot(Kc, KH, dL + KH * h, zero2); };           // K[c][KH h..] d[KH h..]
     auto a_times = [&](int q) __attribute__((always_inline)) {                                                 // A[r_q][:] dx
-        const pair acc = dot(Ar[q], NC, dxL, zero2);
+        const pair acc = dot(Ar[q], NCT, dxL, zero2);
         return acc[0] + acc[1];
     };
     auto fold = [&](pair v) __attribute__((always_inline)) { return v[0] + v[1]; };
     // lanes hand vectors to each other through LDS inside the wave: a wavefront-scope release + wave barrier orders the
     // hand-off for the compiler (the hardware already executes a wave's LDS operations in order)
     auto handoff = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (NWV > 1) {
+            __syncthreads();                                            // the vectors cross between the two waves
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // maximum over the whole instance (all waves); every lane gets it
+    auto inst_tmax = [&](T v, int slot) __attribute__((always_inline)) {
+        v = wave_tmax(v);
+        if constexpr (NWV > 1) {
+            if (lane == 0) redL[wv][slot] = v;
+            __syncthreads();
+            v = wtmax(redL[0][slot], redL[1][slot]);
+        }
+        return v;
     };
     auto all_parts = [&](T v) __attribute__((always_inline)) {          // sum over the HALF parts of a column
         if constexpr (HALF == 2) v += (T)__shfl_xor(v, 32, 64);
@@ -174,7 +197,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
         T w0 = (T)0, w1 = (T)0, w2 = (T)0;
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
-            nuL[lane + 64 * q] = (T)lam[q];
+            nuL[r0 + 64 * q] = (T)lam[q];
             w0 = wtmax(w0, (T)fabs((T)(zt[q] - z[q])));
             w1 = wtmax(w1, (T)fabs((T)zt[q]));
             w2 = wtmax(w2, (T)fabs((T)z[q]));
@@ -182,13 +205,14 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
         handoff();
         const T t3 = all_parts(fold(at_times(zero2)));                  // A' lam
         hx = all_parts(fold(h_times(zero2)));                           // H x
-        const T v0 = wave_tmax(w0);
-        const T v1 = wave_tmax(w1);
-        const T v2 = wave_tmax(w2);
-        const T v3 = wave_tmax((T)fabs(hx + t3 + gc));
-        const T v4 = wave_tmax((T)fabs(hx));
-        const T v5 = wave_tmax((T)fabs(t3));
-        const T v6 = wave_tmax((T)fabs(gc));
+        const T v0 = inst_tmax(w0, 0);
+        const T v1 = inst_tmax(w1, 1);
+        const T v2 = inst_tmax(w2, 2);
+        const T v3 = inst_tmax((T)fabs(hx + t3 + gc), 3);
+        const T v4 = inst_tmax((T)fabs(hx), 4);
+        const T v5 = inst_tmax((T)fabs(t3), 5);
+        const T v6 = inst_tmax((T)fabs(gc), 6);
+        if constexpr (NWV > 1) __syncthreads();                         // redL is reused by the next check
         o_pri = v0;
         o_dua = v3;
         const T num = v0 / wtmax(v1, v2);                               // :315
@@ -205,7 +229,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
             const double p = zt[q] - z[q];
             const double lh = lam[q] + (double)rv[q] * p;
             lam[q] = lh;
-            nuL[lane + 64 * q] = (T)(lh + (double)rv[q] * p);
+            nuL[r0 + 64 * q] = (T)(lh + (double)rv[q] * p);
         }
         handoff();
         {                                                               // column role: d = H x + g + A' nu ; dx = -K d
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
                 ri += 1;
             else if (rho_est < (T)a.rhos[ri] / tolT && ri > 0)                    // :226
                 ri -= 1;
-            if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && lane == 0) {
+            if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && threadIdx.x == 0) {
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
                 tr[0] = (double)pri; tr[1] = (double)dua; tr[2] = (double)rho_est; tr[3] = (double)ri_before;
             }
@@ -259,10 +283,16 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
     double jp = (h == 0 && cok) ? (double)((T)x * ((T)0.5 * hx + gc)) : 0.0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
+    if constexpr (NWV > 1) {
+        __shared__ double jpL[NWV];
+        if (lane == 0) jpL[wv] = jp;
+        __syncthreads();
+        jp = jpL[0] + jpL[1];
+    }
 
     // ---- update_results (:278-305) and the persistent state
     if (a.out_x && h == 0 && cok) ((T*)a.out_x)[(size_t)b * n + c] = (T)x;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
@@ -275,7 +305,7 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
     if (h == 0 && cok) a.x[(size_t)b * n + c] = a.warm_starting ? x : 0.0;           // state persists (:304) or is cleared (:324-333)
 #pragma unroll
     for (int q = 0; q < RL; ++q) {
-        const int r = lane + 64 * q;
+        const int r = r0 + 64 * q;
         if (r < m) {
             if (a.out_z) ((T*)a.out_z)[(size_t)b * m + r] = (T)z[q];
             if (a.out_lam) ((T*)a.out_lam)[(size_t)b * m + r] = (T)lam[q];
@@ -285,10 +315,13 @@ __global__ void __launch_bounds__(64, (WOcc<T, NC, MC>::value)) k_admm_wave(Solv
     }
 }
 
-// 0: does not fit; 1: <T, 32, 64>; 2: <float, 32, 128>
+// 0: does not fit; 1: <T, 32, 64>; 2: <float, 32, 128>; 3: <float, 32, 64, 2> (two wavefronts per instance)
 static int wave_class(const rqp_handle* h) {
     if (h->n <= 32 && h->m <= 64) return 1;
     if (h->esz == 4 && h->n <= 32 && h->m <= 128) return 2;
+    // two wavefronts per instance: measured 0.72x the mid resident tile (n <= 56, m <= 128) but 1.96x the big tile, so it
+    // only takes the sizes the mid tile cannot hold
+    if (h->esz == 4 && h->n > 56 && h->n <= 64 && h->m <= 128) return 3;
     return 0;
 }
 
@@ -296,7 +329,9 @@ bool rqp_wave_fits(const rqp_handle* h) { return wave_class(h) != 0; }
 
 hipError_t rqp_launch_solve_wave(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
     const int wc = wave_class(h);
-    if (wc == 2)
+    if (wc == 3)
+        k_admm_wave<float, 32, 64, 2><<<h->B, 128, 0, s>>>(a);
+    else if (wc == 2)
         k_admm_wave<float, 32, 128><<<h->B, 64, 0, s>>>(a);
     else if (h->esz == 4)
         k_admm_wave<float, 32, 64><<<h->B, 64, 0, s>>>(a);

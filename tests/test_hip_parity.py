@@ -349,6 +349,8 @@ def test_wave_equals_generic_small_problems(prec, tol):
     (31, 7, 50, "wave"),           # n, m not multiples of 4 / of the half-wave split
     (32, 8, 120, "wave"),          # two rows per lane: exactly the n=32, m=128 variant
     (19, 5, 72, "wave"),           # ... with padding in both directions (m = 77)
+    (64, 16, 112, "wave"),         # two wavefronts per instance (56 < n <= 64, m <= 128): exactly n=64, m=128
+    (57, 14, 100, "wave"),         # ... padding in both directions
     (5, 2, 9, "wave"),
     (33, 8, 57, "resident2"),      # one past it -> mid tile
     (56, 14, 114, "resident2"),    # exactly the mid tile (n=56, m=128)

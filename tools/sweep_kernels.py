@@ -49,11 +49,11 @@ def main():
     bad = 0
     for case in range(ncase):
         # ---- one-wavefront kernel vs streaming kernel
-        n = int(rs.randint(2, 33))
+        n = int(rs.randint(2, 33) if rs.rand() < 0.7 else rs.randint(57, 65))     # 57..64: the two-wavefront variant
         n_eq = int(rs.randint(0, max(1, min(n, 8))))
         m = int(rs.randint(max(n_eq + 1, 2), 65 if rs.rand() < 0.5 else 129))     # both one-wavefront variants
         B = int(rs.choice([1, 3, 17, 64, 300]))
-        prec = torch.float32 if (rs.rand() < 0.6 or m > 64) else torch.float64
+        prec = torch.float32 if (rs.rand() < 0.6 or m > 64 or n > 32) else torch.float64
         eps = float(rs.choice([1e-3, 1e-4]))
         H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, m - n_eq, seed0=1000 * case, feasible=True)
         mw, rw = solve(H, g, A, l, u, prec, {"RQP_FORCE_GENERIC": "0"}, eps_abs=eps)
