@@ -57,35 +57,47 @@ def parse():
 
 
 def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
-    """Oracle (reference-faithful W form, float64, one instance at a time, BLAS threads = all
-    host cores: how the reference runs on CPU) on the first instances of the batch until the
-    time budget is spent.  Returns solve-only QP/s (setup amortised, like `value`)."""
+    """Oracle (reference-faithful W form, float64, one instance at a time: how the reference runs on CPU) on the first
+    instances of the batch until the time budget is spent.  BLAS threads are capped at 8: the (n+2m)^2 = 700^2 matvec
+    does not scale further (tools/cpu_baseline_threads.py on the GPU box: 171 QP/s on 1 thread, 365 on 4-16, 60 on 64,
+    23 on 256), so this is the host's best configuration, not its worst.  Returns solve-only QP/s (setup amortised,
+    like `value`)."""
     from oracle import reluqp_oracle as O
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        avail = os.cpu_count() or 1
+    cores = min(8, avail)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:                      # threadpoolctl missing: BLAS keeps its default (all cores)
+        limiter, cores = None, avail
     t_setup = t_solve = 0.0
     iters = 0
     done = 0
-    t0 = time.perf_counter()
     shared = H.ndim == 2                      # linear MPC: one (H, A) for the whole batch
-    while done < g.shape[0] and (time.perf_counter() - t0) < budget_s:
-        qp = O.OracleQP(form="W", quirks=False)
-        qp.setup(H if shared else H[done], g[done], A if shared else A[done], l[done], u[done], eps_abs=eps_abs)
-        r = qp.solve()
-        t_setup += qp.info.setup_time
-        t_solve += r.info.run_time
-        iters += r.info.iter
-        done += 1
+    t0 = time.perf_counter()
+    try:
+        while done < g.shape[0] and (time.perf_counter() - t0) < budget_s:
+            qp = O.OracleQP(form="W", quirks=False)
+            qp.setup(H if shared else H[done], g[done], A if shared else A[done], l[done], u[done], eps_abs=eps_abs)
+            r = qp.solve()
+            t_setup += qp.info.setup_time
+            t_solve += r.info.run_time
+            iters += r.info.iter
+            done += 1
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
     return {
         "value": done / t_solve,
         "unit": "QP/s",
         "cores": cores,
         "kind": "port",
         "sample": "first %d instances of the same batch, oracle W-form fp64 (dense (n+2m)^2 matvec per iteration, "
-                  "numpy/BLAS on %d threads), solve-only; incl. per-QP setup: %.2f QP/s; %.0f ADMM it/s"
-                  % (done, cores, done / (t_solve + t_setup), iters / t_solve),
+                  "numpy/BLAS on %d threads of %d available), solve-only; incl. per-QP setup: %.2f QP/s; %.0f ADMM it/s"
+                  % (done, cores, avail, done / (t_solve + t_setup), iters / t_solve),
         "setup_plus_solve_value": done / (t_solve + t_setup),
         "admm_iters_per_sec": iters / t_solve,
     }
