@@ -245,7 +245,10 @@ def main():
                                "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "GB/s (HBM)",
                                "traffic_source": traffic_src,
                                "kernel": "k_admm_mfma", "kernel_ms": kern_avg_s * 1e3,
-                               "algorithmic_flops_per_launch": sum_iters * f_iter}
+                               "algorithmic_flops_per_launch": sum_iters * f_iter,
+                               "note": "dense algorithmic flops 2*(2mn+2n^2) per instance-iteration; the kernel skips all-zero "
+                                       "operand groups of the block-triangular MPC matrices, so it executes fewer "
+                                       "(profiles/r1_mfma/pmc_admm_mfma.json: MOPS counter)"}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(H, g, A, l, u, args.eps_abs, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
