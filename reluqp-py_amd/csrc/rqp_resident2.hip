@@ -640,11 +640,13 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
 typedef Res2Cfg<10, 13, 4, 13> Cfg2C2;     // n <= 104, m <= 320   (BASELINE: n = 100, m = 300)
 typedef Res2Cfg<2, 4, 2, 4> Cfg2C4;        // n <= 32,  m <= 64    (BASELINE config 4: n = 32, m = 64)
 typedef Res2Cfg<4, 7, 2, 7> Cfg2M;         // n <= 56,  m <= 128
+typedef Res2Cfg<10, 10, 4, 10> Cfg2N;      // n <= 80,  m <= 320   (condensed linear MPC, N = 20, nu = 4: n = 80, m = 320)
 
 static int res2_pick(const rqp_handle* h) {            // smallest tile that holds the problem; -1: none
     if (h->esz != 4) return -1;
     if (h->n <= Cfg2C4::N && h->m <= Cfg2C4::M) return 0;
     if (h->n <= Cfg2M::N && h->m <= Cfg2M::M) return 1;
+    if (h->n <= Cfg2N::N && h->m <= Cfg2N::M) return 3;
     if (h->n <= Cfg2C2::N && h->m <= Cfg2C2::M) return 2;
     return -1;
 }
@@ -661,6 +663,7 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
     switch (res2_pick(h)) {
         case 0: pack_elems_t<Cfg2C4>(h, a_elems, k_elems, h_elems); break;
         case 1: pack_elems_t<Cfg2M>(h, a_elems, k_elems, h_elems); break;
+        case 3: pack_elems_t<Cfg2N>(h, a_elems, k_elems, h_elems); break;
         default: pack_elems_t<Cfg2C2>(h, a_elems, k_elems, h_elems); break;
     }
 }
@@ -676,6 +679,7 @@ hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
     switch (res2_pick(h)) {
         case 0: return pack_t<Cfg2C4>(h, s);
         case 1: return pack_t<Cfg2M>(h, s);
+        case 3: return pack_t<Cfg2N>(h, s);
         default: return pack_t<Cfg2C2>(h, s);
     }
 }
@@ -728,6 +732,7 @@ hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStr
     switch (res2_pick(h)) {
         case 0: return solve_t<Cfg2C4>(h, a, s);
         case 1: return solve_t<Cfg2M>(h, a, s);
+        case 3: return solve_t<Cfg2N>(h, a, s);
         default: return solve_t<Cfg2C2>(h, a, s);
     }
 }

@@ -355,6 +355,8 @@ def test_wave_equals_generic_small_problems(prec, tol):
     (33, 8, 57, "resident2"),      # one past it -> mid tile
     (56, 14, 114, "resident2"),    # exactly the mid tile (n=56, m=128)
     (57, 14, 115, "resident2"),    # one past it -> big tile
+    (80, 20, 300, "resident2"),    # exactly the n <= 80 tile (n=80, m=320)
+    (81, 20, 280, "resident2"),    # one past it -> big tile
     (104, 26, 294, "resident2"),   # exactly the big tile (n=104, m=320)
     (105, 26, 294, "generic"),     # one past it -> streaming kernel
     (100, 25, 296, "generic"),     # m = 321 > 320 -> streaming kernel
