@@ -8,19 +8,28 @@
 One "step" = one batched cold-start solve() of the per-GPU batch (default: 4096 random
 dense QPs, n=100, m=300, float32, feasible rand_qp generator of SURVEY.md 8(d), eps_abs
 1e-3, all reference defaults), inputs and the K(rho) table already resident in HBM.
-Instances are independent: each rank owns its own shard (weak scaling: 4096 per GPU),
-there is NO data-path collective; torch.distributed is used only for the barrier around
-the timed region and for the max-over-ranks / sum reductions of the reported numbers.
+Instances are independent: each rank owns its own shard, there is NO data-path collective;
+torch.distributed is used only for the barrier around the timed region and for the
+max-over-ranks / sum reductions of the reported numbers.
+
+  --scaling weak    (default) every rank solves --batch instances: the job grows with N
+  --scaling strong  --batch is the GLOBAL batch, split contiguously over the ranks (D.shard_range)
+  --workload random_qp | mpc (BASELINE config 3) | c4 (BASELINE config 4: n=32, m=64, 8192 per GPU = 65536 on 8 GPUs)
 
 Rank 0 prints ONE JSON line.  `value` = all QPs solved by all ranks / max-over-ranks time.
-`roofline` prices the ADMM kernel against the HBM roof using the ALGORITHMIC bytes of
-SURVEY.md 8(d): 4*(n^2 + m*n) bytes per instance-iteration (K and A streamed once); the
-resident design may exceed 1.0 of that roof.  `cpu_baseline` times the oracle
-(reference-faithful W-form, float64) on a bounded sample on the host cores.
+`roofline` prices the ADMM kernel against the roof that BINDS it:
+  resident2 / wave : "valu" -- matrices live in registers, HBM is out of the picture; algorithmic flops
+                     (2n^2 + 4mn per instance-iteration) / kernel time / 157.3 TF fp32 vector peak
+  mfma             : "mfma" -- the same flops against the 157.3 TF fp32 matrix peak
+  generic          : "hbm"  -- algorithmic bytes 4(n^2 + mn) per instance-iteration / kernel time / 8 TB/s
+`hbm_algorithmic_x` keeps the streaming-model GB/s figure (may exceed the HBM peak for the resident kernels: the
+matrices are not re-read).  `cpu_baseline` times the oracle on the host cores in child processes started BEFORE this
+process touches the GPU.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,11 +39,11 @@ for _p in (REPO, os.path.join(REPO, "reluqp-py_amd")):
         sys.path.insert(0, _p)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (f32 in / f32 acc) dense peak
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: vector fp64 peak
 
 
 def parse():
@@ -42,92 +51,147 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak) / in total (strong); default 4096 "
+                                                             "(c4: 8192 weak, 65536 strong)")
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--n-eq", type=int, default=25)
     ap.add_argument("--n-ineq", type=int, default=275)
     ap.add_argument("--eps-abs", type=float, default=1e-3)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg, split over its modes (0 = skip)")
     ap.add_argument("--seed0", type=int, default=0)
-    ap.add_argument("--workload", choices=["random_qp", "mpc"], default="random_qp",
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--kernel", default="auto", help="C-ABI kernel request (auto | generic | resident | wave | mfma)")
+    ap.add_argument("--tile", choices=["same", "f16"], default="same", help="K(rho) tile storage (BASELINE config 5: f16)")
+    ap.add_argument("--workload", choices=["random_qp", "mpc", "c4"], default="random_qp",
                     help="random_qp: the headline metric's workload (default); mpc: BASELINE config 3, batch of condensed "
-                         "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A")
-    return ap.parse_args()
+                         "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A; c4: BASELINE config 4, "
+                         "random dense QPs n=32, m=64")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: child process of the cpu_baseline leg
+    a = ap.parse_args()
+    if a.workload == "c4":
+        a.n, a.n_eq, a.n_ineq = 32, 8, 56
+        if a.batch is None:
+            a.batch = 65536 if a.scaling == "strong" else 8192
+    if a.batch is None:
+        a.batch = 4096
+    return a
 
 
-def cpu_baseline(H, g, A, l, u, eps_abs, budget_s):
-    """Oracle (reference-faithful W form, float64, one instance at a time: how the reference runs on CPU) on the first
-    instances of the batch until the time budget is spent.  BLAS threads are capped at 8: the (n+2m)^2 = 700^2 matvec
-    does not scale further (tools/cpu_baseline_threads.py on the GPU box: 171 QP/s on 1 thread, 365 on 4-16, 60 on 64,
-    23 on 256), so this is the host's best configuration, not its worst.  Returns solve-only QP/s (setup amortised,
-    like `value`)."""
+# ------------------------------------------------------------------------------------------------ cpu_baseline leg
+def _mpc_controller():
+    from reluqp import mpc
+    Adyn, Bdyn = mpc.random_plant(12, 4, seed=0)                      # one plant, the batch is the initial states
+    return mpc.LinearMPC(Adyn, Bdyn, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
+
+
+def cpu_worker(args):
+    """Child process of the cpu_baseline leg: never imports torch / touches the GPU.  Spec "form:dtype:rank:P:budget".
+    Solves instances rank, rank+P, ... of the bench batch with the oracle until the budget is spent; prints one JSON."""
+    form, dtype, rank, P, budget = args.cpu_worker.split(":")
+    rank, P, budget = int(rank), int(P), float(budget)
     from oracle import reluqp_oracle as O
+    from reluqp import utils
+    dt = np.float32 if dtype == "f32" else np.float64
+    ctl = x0 = None
+    if args.workload == "mpc":
+        ctl = _mpc_controller()
+        x0 = np.random.RandomState(args.seed0 + 1).randn(args.batch, 12)
+    t_setup = t_solve = 0.0
+    iters = done = 0
+    idx = rank
+    t0 = time.perf_counter()
+    while idx < args.batch and (time.perf_counter() - t0) < budget:
+        if ctl is not None:
+            g, l, u = ctl.qp_vectors(x0[idx:idx + 1])
+            H, A, g, l, u = ctl.H, ctl.A, g[0], l[0], u[0]
+        else:
+            H, g, A, l, u, _ = utils.rand_qp(args.n, args.n_eq, args.n_ineq, seed=args.seed0 + idx, compute_sol=False,
+                                             feasible=True)
+        qp = O.OracleQP(form=form, quirks=False)
+        qp.setup(H, g, A, l, u, eps_abs=args.eps_abs, dtype=dt)
+        r = qp.solve()
+        t_setup += qp.info.setup_time
+        t_solve += r.info.run_time
+        iters += r.info.iter
+        done += 1
+        idx += P
+    print(json.dumps({"done": done, "t_solve": t_solve, "t_setup": t_setup, "iters": iters}))
+
+
+def _run_cpu_mode(args, form, dtype, procs, threads, budget):
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env[k] = str(threads)
+    base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch), "--n", str(args.n),
+            "--n-eq", str(args.n_eq), "--n-ineq", str(args.n_ineq), "--eps-abs", str(args.eps_abs), "--seed0", str(args.seed0)]
+    ps = [subprocess.Popen(base + ["--cpu-worker", "%s:%s:%d:%d:%g" % (form, dtype, r, procs, budget)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(procs)]
+    outs = []
+    for p in ps:
+        so, se = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed: " + se[-400:])
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    done = sum(o["done"] for o in outs)
+    # all workers are busy for the whole budget, so the job's rate is the sum of the per-worker rates
+    qps = sum(o["done"] / o["t_solve"] for o in outs if o["t_solve"] > 0)
+    qps_setup = sum(o["done"] / (o["t_solve"] + o["t_setup"]) for o in outs if o["t_solve"] > 0)
+    its = sum(o["iters"] / o["t_solve"] for o in outs if o["t_solve"] > 0)
+    return {"form": form, "dtype": dtype, "processes": procs, "threads_per_process": threads, "cores": procs * threads,
+            "instances": done, "value": qps, "setup_plus_solve_value": qps_setup, "admm_iters_per_sec": its}
+
+
+def cpu_baseline(args):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the oracle (kind "port"; the reference's Python cannot travel) on the host
+    cores, on the first instances of the same workload, three modes of budget/3 seconds each:
+      (i)   W form float64, 1 process x 8 BLAS threads  -- how the reference would run (the 700^2 matvec does not scale
+            past ~8 threads: tools/cpu_baseline_threads.py)
+      (ii)  W form float64, P processes x 1 thread, instances sharded -- best-case throughput of the reference formulation
+      (iii) factored float32 ("refine" statement, what the GPU kernels execute), P x 1 thread -- the stronger baseline, so
+            that the GPU/CPU ratio is not inflated by the W form's 7x extra flops
+    `value` = the best reference-faithful (W form) mode; P = min(available cores, 16) (the GPU box's CPU share)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = min(8, avail)
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=cores)
-    except Exception:                      # threadpoolctl missing: BLAS keeps its default (all cores)
-        limiter, cores = None, avail
-    t_setup = t_solve = 0.0
-    iters = 0
-    done = 0
-    shared = H.ndim == 2                      # linear MPC: one (H, A) for the whole batch
-    t0 = time.perf_counter()
-    try:
-        while done < g.shape[0] and (time.perf_counter() - t0) < budget_s:
-            qp = O.OracleQP(form="W", quirks=False)
-            qp.setup(H if shared else H[done], g[done], A if shared else A[done], l[done], u[done], eps_abs=eps_abs)
-            r = qp.solve()
-            t_setup += qp.info.setup_time
-            t_solve += r.info.run_time
-            iters += r.info.iter
-            done += 1
-    finally:
-        if limiter is not None:
-            limiter.restore_original_limits()
+    P = max(1, min(avail, 16))
+    per = args.cpu_seconds / 3.0
+    modes = [_run_cpu_mode(args, "W", "f64", 1, min(8, avail), per),
+             _run_cpu_mode(args, "W", "f64", P, 1, per),
+             _run_cpu_mode(args, "refine", "f32", P, 1, per)]
+    best = max(modes[:2], key=lambda mo: mo["value"])
     return {
-        "value": done / t_solve,
-        "unit": "QP/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "first %d instances of the same batch, oracle W-form fp64 (dense (n+2m)^2 matvec per iteration, "
-                  "numpy/BLAS on %d threads of %d available), solve-only; incl. per-QP setup: %.2f QP/s; %.0f ADMM it/s"
-                  % (done, cores, avail, done / (t_solve + t_setup), iters / t_solve),
-        "setup_plus_solve_value": done / (t_solve + t_setup),
-        "admm_iters_per_sec": iters / t_solve,
+        "value": best["value"], "unit": "QP/s", "cores": best["cores"], "kind": "port",
+        "sample": "oracle W form (reference-faithful dense (n+2m)^2 matvec per iteration) float64 on the first %d instances "
+                  "of the same workload, %d process(es) x %d thread(s), %.0f s; solve-only (setup amortised like `value`); "
+                  "host has %d cores available" % (best["instances"], best["processes"], best["threads_per_process"], per, avail),
+        "setup_plus_solve_value": best["setup_plus_solve_value"], "admm_iters_per_sec": best["admm_iters_per_sec"],
+        "modes": modes,
+        "factored_f32_value": modes[2]["value"],
     }
 
 
+# ------------------------------------------------------------------------------------------------ PMC traffic
 def pmc_traffic(kernel, args, kern_s):
-    """HBM traffic of the dominant kernel in GB/s from the PMC passes committed under profiles/ (counters cannot be
-    read from inside this process; the passes are separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
-    this same command).  KB units, FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md).  None when no profile of this
-    kernel on this workload is committed."""
-    sig = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision)
+    """HBM traffic of the dominant kernel in GB/s from the PMC passes committed under profiles/ for THIS round's build
+    (counters cannot be read from inside this process; the passes are separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` runs of this same command, tools/pmc_collect.sh).  KB units, FETCH_SIZE doubled on gfx950
+    (MI355X_MICROARCH.md).  None when no profile of this kernel on this workload is committed."""
+    sig = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision, args.tile)
     table = {
-        ("resident2", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_resident2/pmc_admm_res2.json",
-        ("resident", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_resident/pmc_admm_resident.json",
-        ("generic", ("random_qp", 4096, 100, 25, 275, "f32")): "r1_generic/pmc_admm_generic.json",
-        ("wave", ("random_qp", 65536, 32, 8, 56, "f32")): "r1_wave/pmc_hbm.json",
+        ("resident2", ("random_qp", 4096, 100, 25, 275, "f32", "same")): "r2_resident2/pmc.json",
+        ("mfma", ("mpc", 4096, 100, 25, 275, "f32", "same")): "r2_mfma/pmc.json",
+        ("wave", ("c4", 8192, 32, 8, 56, "f32", "same")): "r2_wave/pmc.json",
     }
     name = table.get((kernel, sig))
-    if name is None and kernel == "mfma" and args.workload == "mpc" and args.batch == 4096 and args.precision == "f32":
-        name = "r1_mfma/pmc_hbm_b4096.json"
     if name is None:
         return None, None
     path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
             pm = json.load(f)
-        if "hbm_bytes_per_launch" in pm:
-            nbytes = float(pm["hbm_bytes_per_launch"])
-        else:
-            nbytes = (2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])) * 1024.0
+        nbytes = (2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])) * 1024.0
     except (OSError, KeyError, ValueError):
         return None, None
     return nbytes / kern_s / 1e9, "profiles/" + name + " (bytes per launch / this run's kernel time)"
@@ -135,6 +199,15 @@ def pmc_traffic(kernel, args, kern_s):
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        cpu_worker(args)
+        return
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = None
+    if world_env == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(args)          # child processes, finished before this process initialises the GPU
+
+    import torch
     from reluqp import distributed as D
     rank, world, local_rank, dist = D.init()          # nccl (= RCCL) when WORLD_SIZE > 1; barrier/reductions only
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
@@ -144,28 +217,29 @@ def main():
     import reluqp.reluqpth as reluqpth
     from reluqp import utils
 
-    B, n, m = args.batch, args.n, args.n_eq + args.n_ineq
+    n, m = args.n, args.n_eq + args.n_ineq
     prec = torch.float32 if args.precision == "f32" else torch.float64
     esz = 4 if args.precision == "f32" else 8
-    # weak scaling: the job is world*B instances; rank r owns the contiguous shard [r*B, (r+1)*B)
-    start, size = D.shard_range(world * B, rank, world)
-    assert size == B
+    if args.scaling == "weak":      # the job is world*batch instances; rank r owns the contiguous shard [r*B, (r+1)*B)
+        start, B = D.shard_range(world * args.batch, rank, world)
+    else:                           # the job is `batch` instances in total, split contiguously
+        start, B = D.shard_range(args.batch, rank, world)
     if args.workload == "mpc":
-        from reluqp import mpc
-        Adyn, Bdyn = mpc.random_plant(12, 4, seed=0)                      # one plant, the batch is the initial states
-        ctl = mpc.LinearMPC(Adyn, Bdyn, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
-        x0 = np.random.RandomState(args.seed0 + 1 + rank).randn(B, 12)
+        ctl = _mpc_controller()
+        x0 = np.random.RandomState(args.seed0 + 1).randn(start + B, 12)[start:]
         H, A = ctl.H, ctl.A                                               # shared by the batch (un-batched)
         g, l, u = ctl.qp_vectors(x0)
         n, m = H.shape[0], A.shape[0]
     else:
-        H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + start, feasible=True)
+        H, g, A, l, u, xs = utils.rand_qp_batch(B, n, args.n_eq, args.n_ineq, seed0=args.seed0 + start, feasible=True,
+                                                dtype=np.float32 if args.precision == "f32" else np.float64)
     # inputs resident in HBM in the working dtype before anything is timed (host->device of 655 MB is data loading)
     Hd, gd, Ad, ld, ud = (torch.from_numpy(np.ascontiguousarray(t)).to(device=dev, dtype=prec) for t in (H, g, A, l, u))
     torch.cuda.synchronize(dev)
     model = reluqpth.ReLU_QP()
     t0 = time.perf_counter()
-    model.setup(Hd, gd, Ad, ld, ud, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False)
+    model.setup(Hd, gd, Ad, ld, ud, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False, kernel=args.kernel,
+                iterate_dtype=torch.float16 if args.tile == "f16" else None)
     torch.cuda.synchronize(dev)
     setup_s = time.perf_counter() - t0
 
@@ -188,27 +262,46 @@ def main():
     iters = res.info.iter.to(torch.float64)
     sum_iters = float(iters.sum())
     solved = float((res.info.status_code == 0).sum())
-    elapsed, (kern_avg_s, setup_max), tot_iters, tot_solved, tot_qps = D.reduce_report(
-        dist, dev, elapsed, sum_iters, solved, B, extra_max=[kern_s / max(1, args.steps), setup_s])
+    elapsed, (kern_avg_s, setup_max, rank_iters_max), tot_iters, tot_solved, tot_qps = D.reduce_report(
+        dist, dev, elapsed, sum_iters, solved, B, extra_max=[kern_s / max(1, args.steps), setup_s, sum_iters])
 
     if rank == 0:
         step_s = elapsed / args.steps
         value = tot_qps / step_s
-        # algorithmic work per launch (one rank's launch): SURVEY.md 8(d)
+        # algorithmic work per launch (one rank's launch: the slowest rank's time against the largest rank's work): SURVEY.md 8(d)
         b_iter = esz * (n * n + m * n)
         f_iter = 2 * n * n + 4 * m * n
-        alg_bytes = sum_iters * b_iter
-        achieved = alg_bytes / kern_avg_s / 1e9
+        alg_bytes = rank_iters_max * b_iter
+        alg_flops = rank_iters_max * f_iter
+        hbm_gbs = alg_bytes / kern_avg_s / 1e9
+        tf = alg_flops / kern_avg_s / 1e12
         traffic, traffic_src = pmc_traffic(model.kernel, args, kern_avg_s)
         if args.workload == "mpc":
-            wl = ("batch=%d/GPU condensed linear-MPC QPs (horizon 20, nx=12, nu=4: n=%d, m=%d), H and A shared by the "
-                  "batch, random initial states seed %d.., eps_abs=%g, cold start, reference defaults"
-                  % (B, n, m, args.seed0 + 1, args.eps_abs))
-            metric = "QP solves/sec (batch=%d linear-MPC QPs n=%d m=%d per GPU)" % (B, n, m)
+            wl = ("batch=%d%s condensed linear-MPC QPs (horizon 20, nx=12, nu=4: n=%d, m=%d), H and A shared by the "
+                  "batch, random initial states seed %d, eps_abs=%g, cold start, reference defaults"
+                  % (args.batch, "/GPU" if args.scaling == "weak" else " total", n, m, args.seed0 + 1, args.eps_abs))
+            metric = "QP solves/sec (batch=%d linear-MPC QPs n=%d m=%d)" % (args.batch, n, m)
         else:
-            wl = ("batch=%d/GPU random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds %d.., eps_abs=%g, cold "
-                  "start, reference defaults" % (B, n, m, args.n_eq, args.seed0, args.eps_abs))
-            metric = "QP solves/sec (batch=%d random dense QPs n=%d m=%d per GPU)" % (B, n, m)
+            wl = ("batch=%d%s random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds %d.., eps_abs=%g, cold "
+                  "start, reference defaults" % (args.batch, "/GPU" if args.scaling == "weak" else " total", n, m, args.n_eq,
+                                                 args.seed0, args.eps_abs))
+            metric = "QP solves/sec (batch=%d random dense QPs n=%d m=%d)" % (args.batch, n, m)
+        kname = "k_admm_%s" % {"resident2": "res2"}.get(model.kernel, model.kernel)
+        if model.kernel == "mfma":
+            roof = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                    "note": "dense algorithmic flops 2n^2+4mn per instance-iteration; the kernel skips all-zero operand groups of the "
+                            "block-triangular MPC matrices, so it executes fewer"}
+        elif model.kernel == "generic":
+            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
+        else:
+            peak = FP32_VALU_PEAK_TFLOPS if args.precision == "f32" else FP64_VALU_PEAK_TFLOPS
+            roof = {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                    "note": "A and K live in registers for the whole solve (HBM traffic = `traffic`, far below the streaming model); "
+                            "the binding roof is %s vector FMA issue" % args.precision}
+        roof.update({"traffic": traffic, "traffic_unit": "GB/s (HBM, PMC)", "traffic_source": traffic_src,
+                     "kernel": kname, "kernel_ms": kern_avg_s * 1e3,
+                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                     "hbm_algorithmic_gbs": hbm_gbs, "hbm_algorithmic_x": hbm_gbs / HBM_PEAK_GBS})
         out = {
             "metric": metric,
             "value": value,
@@ -218,40 +311,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": wl,
                        "global_batch": int(tot_qps), "parallelism": "batch-split x%d, no collectives" % world,
-                       "kernel": model.kernel},
+                       "kernel": model.kernel, "tile": args.tile},
             "admm_iters_per_sec": tot_iters / step_s,
             "mean_iters": tot_iters / tot_qps,
             "solved_frac": tot_solved / tot_qps,
             "setup_s": setup_max,
             "setup_plus_solve_qps": tot_qps / (setup_max + step_s),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_admm_%s" % model.kernel, "kernel_ms": kern_avg_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "fp32_valu_tflops": sum_iters * f_iter / kern_avg_s / 1e12,
-                         "fp32_valu_frac": sum_iters * f_iter / kern_avg_s / 1e12 / FP32_VALU_PEAK_TFLOPS},
+            "roofline": roof,
         }
-        if model.kernel == "mfma":
-            # the batch is the N axis of fp32 MFMA GEMMs: price against the fp32 matrix peak with the dense
-            # algorithmic flops 2*(2mn + 2n^2) per instance-iteration ("k_admm_mfma")
-            tf = sum_iters * f_iter / kern_avg_s / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "GB/s (HBM)",
-                               "traffic_source": traffic_src,
-                               "kernel": "k_admm_mfma", "kernel_ms": kern_avg_s * 1e3,
-                               "algorithmic_flops_per_launch": sum_iters * f_iter,
-                               "note": "dense algorithmic flops 2*(2mn+2n^2) per instance-iteration; the kernel skips all-zero "
-                                       "operand groups of the block-triangular MPC matrices, so it executes fewer "
-                                       "(profiles/r1_mfma/pmc_admm_mfma.json: MOPS counter)"}
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(H, g, A, l, u, args.eps_abs, args.cpu_seconds)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
+            out["gpu_over_cpu_factored_f32"] = value / cpu["factored_f32_value"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

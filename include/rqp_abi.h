@@ -36,19 +36,42 @@ typedef struct rqp_handle rqp_handle;
 
 enum rqp_dtype { RQP_F32 = 0, RQP_F64 = 1 };
 
+/* Storage type of the preconditioner tile K_j in the register-resident kernels (BASELINE
+ * config 5, SURVEY.md 7.3 "matrix tile fp16, x/z/lam and residual fp32").  K only
+ * preconditions the residual correction dx = -K d: its rounding
+ * changes the convergence rate, never the fixed point; H, A and every residual stay in
+ * dims.dtype.  RQP_TILE_F16 needs dims.dtype == RQP_F32.                               */
+enum rqp_tile_dtype { RQP_TILE_SAME = 0, RQP_TILE_F16 = 1 };
+
+/* Solve-kernel request (rqp_dims.kernel).  AUTO = measured dispatch by size / batch /
+ * sharing; an explicit kernel that cannot hold the problem makes rqp_setup return
+ * RQP_ERR_UNSUPPORTED (nothing falls back silently).                                    */
+enum rqp_kernel {
+    RQP_KERNEL_AUTO = 0,
+    RQP_KERNEL_GENERIC = 1,   /* streaming, any n, m, f32/f64                              */
+    RQP_KERNEL_RESIDENT = 2,  /* A, K in VGPRs, one workgroup per instance (f32; f64 tile) */
+    RQP_KERNEL_WAVE = 3,      /* one wavefront per instance, small problems                */
+    RQP_KERNEL_MFMA = 4       /* shared (H, A): batch on the MFMA N axis                   */
+};
+
 enum rqp_error {
     RQP_OK = 0,
     RQP_ERR_ARG = -1,        /* null pointer / bad dimension / bad setting       */
     RQP_ERR_STATE = -2,      /* call order (e.g. solve before setup)             */
     RQP_ERR_HIP = -3,        /* a HIP runtime call failed: see rqp_last_error    */
     RQP_ERR_OOM = -4,        /* workspace allocation failed                      */
-    RQP_ERR_UNSUPPORTED = -5 /* e.g. Hx/Ax matrix update (reluqpth.py:177)       */
+    RQP_ERR_UNSUPPORTED = -5 /* size / mode no kernel of this build covers        */
 };
 
 /* per-instance exit status written to rqp_info.status (reluqpth.py:236,245) */
 enum rqp_status {
     RQP_STATUS_SOLVED = 0,          /* "solved"             */
     RQP_STATUS_MAX_ITER = 1,        /* "max_iters_reached"  */
+    RQP_STATUS_NAN = 2,             /* "nan_detected": a residual of the last check is NaN (Q17 made visible;
+                                       only raised when the iteration budget is spent -- the loop control is
+                                       the reference's)                                                        */
+    RQP_STATUS_PRIMAL_INFEASIBLE = 3, /* "primal_infeasible": certificate found (check_infeasibility)          */
+    RQP_STATUS_DUAL_INFEASIBLE = 4,   /* "dual_infeasible"                                                     */
     RQP_STATUS_UNSOLVED = -1        /* never solved          */
 };
 
@@ -58,6 +81,8 @@ typedef struct rqp_dims {
     int32_t batch;        /* independent instances (>= 1)                             */
     int32_t shared_mats;  /* 1: one (H, A) shared by all instances (linear MPC)       */
     int32_t dtype;        /* rqp_dtype of every data pointer                          */
+    int32_t kernel;       /* rqp_kernel request (0 = auto)                            */
+    int32_t tile_dtype;   /* rqp_tile_dtype of the resident K tile (0 = same as dtype) */
     int32_t reserved;
 } rqp_dims;
 
@@ -74,6 +99,15 @@ typedef struct rqp_settings {
     int32_t max_iter;              /* 4000  */
     int32_t check_interval;        /* 25    */
     int32_t warm_starting;         /* 1     */
+    /* --- extensions (all default to the reference's behaviour) --- */
+    double eps_rel;                /* 0: absolute test only (reluqpth.py:233).  > 0: OSQP-style
+                                      pri < eps_abs*sqrt(m) + eps_rel*max(|Ax|,|z|),
+                                      dua < eps_abs*sqrt(n) + eps_rel*max(|Hx|,|A'lam|,|g|)  (inf-norms)   */
+    double eps_prim_inf;           /* 1e-4  certificate tolerances (check_infeasibility)                    */
+    double eps_dual_inf;           /* 1e-4  */
+    int32_t scaling;               /* 0: none (the reference's `scaling` is an unused TODO, reluqpth.py:105);
+                                      k > 0: k Ruiz equilibration passes at setup, results un-scaled          */
+    int32_t check_infeasibility;   /* 0.  1: test the OSQP certificates at every check                       */
 } rqp_settings;
 
 /* Per-instance results of one solve (classes.py:67-88), struct of DEVICE arrays,
@@ -110,9 +144,15 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
               const void* u, void* stream);
 
 /* ReLU_QP.update (reluqpth.py:159-183): new g and/or l and/or u ([batch][n] /
- * [batch][m]); NULL = unchanged.  Matrix updates are RQP_ERR_UNSUPPORTED upstream
- * (reluqpth.py:177) and have no entry point here.  State is untouched.          */
+ * [batch][m]); NULL = unchanged.  State is untouched.                           */
 int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void* stream);
+
+/* ReLU_QP.update(Hx=, Ax=) -- rejected upstream (`assert`, reluqpth.py:176-177), SURVEY.md
+ * 8(f)-4: new H and/or A (same shapes as in rqp_setup; NULL = unchanged).  Re-runs the
+ * device setup chain (pack -> A'cA -> K(rho) ladder -> kernel images) on the existing
+ * workspace; g, l, u, the equality pattern c, the ADMM state and the rho indices are kept,
+ * i.e. the next solve is warm-started exactly like after rqp_update.                     */
+int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream);
 
 /* Parametric form of ReLU_QP.update for linear MPC (the x0 update of the reference's driver,
  * loose_code/RandomLinMPC.py / SURVEY.md Appendix C, evaluated on the device in one pass):

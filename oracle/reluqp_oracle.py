@@ -275,6 +275,7 @@ class OracleQP:
         self.l = np.ascontiguousarray(l, dtype=dt)
         self.u = np.ascontiguousarray(u, dtype=dt)
         self.nx, self.nc = self.H.shape[0], self.A.shape[0]
+        self._lu_setup = (self.l.copy(), self.u.copy())    # the equality pattern (rho x 1e3 rows) is fixed at setup
         self.rhos = setup_rhos(st.rho, st.rho_min, st.rho_max, st.adaptive_rho_tolerance,
                                st.adaptive_rho).astype(dt)
         self._build_matrices()
@@ -283,12 +284,13 @@ class OracleQP:
 
     def _build_matrices(self):
         st = self.settings
+        l0, u0 = self._lu_setup
         if self.form == "W":
             self.W_ks, self.B_ks, self.b_ks = setup_matrices_W(
-                self.H, self.g, self.A, self.l, self.u, self.rhos, st.sigma, st.eq_tol)
+                self.H, self.g, self.A, l0, u0, self.rhos, st.sigma, st.eq_tol)
         else:
             self.At = np.ascontiguousarray(self.A.T)
-            self.rho_vecs = [rho_vector(r, self.l, self.u, st.eq_tol) for r in self.rhos]
+            self.rho_vecs = [rho_vector(r, l0, u0, st.eq_tol) for r in self.rhos]
             # K is computed in float64 and rounded to the working dtype: this is
             # what the HIP setup kernel does (fp64 Cholesky)
             H64, A64 = self.H.astype(np.float64), self.A.astype(np.float64)
@@ -320,7 +322,17 @@ class OracleQP:
             self.l = np.ascontiguousarray(l, dtype=dt)
         if u is not None:
             self.u = np.ascontiguousarray(u, dtype=dt)
-        assert Hx is None and Ax is None, "updating Hx and Ax is not supported yet"
+        if Hx is not None or Ax is not None:
+            # The reference asserts here ("updating Hx and Ax is not supported yet", reluqpth.py:176-177).  The build
+            # defines it as: new dense H / A, the matrices of setup_matrices (:40-78) rebuilt with the
+            # equality pattern of setup, state and rho index carried -- this restatement is that definition.
+            assert not self.quirks, "updating Hx and Ax is not supported yet"
+            if Hx is not None:
+                self.H = np.ascontiguousarray(Hx, dtype=dt)
+            if Ax is not None:
+                self.A = np.ascontiguousarray(Ax, dtype=dt)
+            self._build_matrices()
+            self._acc = None
         self.info.update_time = time.perf_counter() - t0
 
     def update_settings(self, **kwargs):

@@ -51,7 +51,9 @@ class Random_QP_benchmark():
         results = model.solve()
         return results.info.solve_time, results.x
 
-    def random_initial_solve(self, nx_min=10, nx_max=100, n_sample=6, n_seeds=5, tol=1e-4):
+    def random_initial_solve(self, nx_min=10, nx_max=100, n_sample=6, n_seeds=5, tol=1e-4, check=None):
+        """reference random_qps.py:47-81.  ``check(nx, seed, tol, x)``: optional cross-solver hook called per solve (the
+        reference compares with OSQP at :68; OSQP is used when importable, tests pass an independent checker)."""
         nx_list = np.geomspace(nx_min, nx_max, num=n_sample)
         rows = []
         for _ in range(3):                                   # warm the runtime (reference: "make sure reluqp is compiled")
@@ -62,6 +64,8 @@ class Random_QP_benchmark():
             for seed in range(n_seeds):
                 t, x = self.reluqpth_solve(nx=nx, n_eq=nx // 4, n_ineq=nx // 4, seed=seed, tol=tol)
                 times.append(t)
+                if check is not None:
+                    check(nx, seed, tol, x)
                 if HAVE_OSQP:
                     to, xo = self.osqp_solve(nx=nx, n_eq=nx // 4, n_ineq=nx // 4, seed=seed, tol=tol)
                     otimes.append(to)

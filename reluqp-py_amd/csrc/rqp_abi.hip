@@ -20,6 +20,10 @@ int fail_arg(rqp_handle* h, const char* what) {
     if (h) h->err = what;
     return RQP_ERR_ARG;
 }
+int fail_unsupported(rqp_handle* h, const char* what) {
+    if (h) h->err = what;
+    return RQP_ERR_UNSUPPORTED;
+}
 
 #define HIP_TRY(h, call)                                      \
     do {                                                      \
@@ -29,7 +33,8 @@ int fail_arg(rqp_handle* h, const char* what) {
 
 bool settings_valid(const rqp_settings& s) {
     return s.rho > 0 && s.rho_min > 0 && s.rho_max >= s.rho_min && s.sigma >= 0 && s.adaptive_rho_tolerance > 1 &&
-           s.eps_abs >= 0 && s.max_iter >= 0 && s.check_interval >= 1;
+           s.eps_abs >= 0 && s.max_iter >= 0 && s.check_interval >= 1 && s.eps_rel >= 0 && s.eps_prim_inf >= 0 &&
+           s.eps_dual_inf >= 0 && s.scaling >= 0;
 }
 
 // setup_rhos, reluqpth.py:20-38: repeated division / multiplication in doubles, sorted.
@@ -67,14 +72,14 @@ int argmin_abs(const std::vector<double>& r, double v) {   // np.argmin(np.abs(r
 void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
-                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img, (void**)&h->queue};
+                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img, (void**)&h->queue,
+                     (void**)&h->flag_d};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     h->is_setup = false;
     h->resident = false;
-    h->res_kind = 0;
     h->use_mfma = false;
     h->use_wave = false;
     h->kernel_name = "generic";
@@ -83,8 +88,7 @@ void free_ws(rqp_handle* h) {
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
     if (h->use_mfma && a.mode == 0) return rqp_launch_solve_mfma(h, a, s);
     if (h->use_wave && a.mode == 0) return rqp_launch_solve_wave(h, a, s);
-    if (h->resident && h->res_kind == 2) return rqp_launch_solve_res2(h, a, s);
-    if (h->resident) return rqp_launch_solve_resident(h, a, s);
+    if (h->resident) return rqp_launch_solve_res2(h, a, s);
     return rqp_launch_solve_generic(h, a, s);
 }
 
@@ -114,6 +118,93 @@ SolveArgs make_solve_args(const rqp_handle* h) {
     return a;
 }
 
+
+SetupArgs make_setup_args(const rqp_handle* h, const void* H, const void* g, const void* A, const void* l, const void* u) {
+    SetupArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = h->n; a.m = h->m; a.ldn = h->ldn; a.ldm = h->ldm; a.nrho = h->nrho; a.B = h->B; a.nmat = h->nmat;
+    a.sigma = h->st.sigma;
+    a.eq_tol = h->st.eq_tol;
+    a.H_in = H; a.A_in = A; a.g_in = g; a.l_in = l; a.u_in = u;
+    a.Ht = h->Ht; a.A = h->A; a.At = h->At; a.K = h->K; a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
+    a.G = h->G;
+    a.rhos = h->rhos_d;
+    a.fscratch = h->fscratch;
+    return a;
+}
+
+// Kernel selection (rqp_dims.kernel; AUTO = measured crossovers).  Pure function of the handle: no environment.
+int select_kernels(rqp_handle* h) {
+    const int req = h->dims.kernel;
+    h->resident = h->use_wave = h->use_mfma = false;
+    h->kernel_name = "generic";
+    switch (req) {
+        case RQP_KERNEL_GENERIC:
+            break;
+        case RQP_KERNEL_RESIDENT:
+            if (!rqp_res2_fits(h)) return fail_unsupported(h, "kernel=resident: needs float32, n <= 104, m <= 320");
+            h->resident = true;
+            break;
+        case RQP_KERNEL_WAVE:
+            if (!rqp_wave_fits(h)) return fail_unsupported(h, "kernel=wave: needs n <= 32, m <= 64 (float32 also n <= 32, m <= 128 and 56 < n <= 64, m <= 128)");
+            h->use_wave = true;
+            break;
+        case RQP_KERNEL_MFMA:
+            if (!rqp_mfma_fits(h)) return fail_unsupported(h, "kernel=mfma: needs float32, shared (H, A), n <= 80, m <= 320");
+            h->use_mfma = true;
+            break;
+        default: {
+            // shared-(H,A) batches large enough to fill the chip with 16-instance tiles go to the MFMA kernel: from ~2k
+            // instances (below, the per-instance kernels still win; crossover measured on the condensed-MPC shape: 1024 ->
+            // resident 1.7x faster, 2048 -> even cold / MFMA 1.3x closed loop, 3072 -> MFMA 1.35x / 1.8x) and only for
+            // problems beyond the small / mid per-instance tiles -- the MFMA tile costs the same whatever the problem size
+            // (minus skipped zero groups); on n=30, m=60 the one-wavefront kernel is 3-4x faster, on n=20, m=80 the mid
+            // resident tile is on par (measured)
+            const bool mfma_pays = h->B >= 2048 && (h->n > 56 || h->m > 128);
+            if (rqp_mfma_fits(h) && mfma_pays)
+                h->use_mfma = true;
+            else if (rqp_wave_fits(h))       // small problems: one wavefront per instance
+                h->use_wave = true;
+            else if (rqp_res2_fits(h))
+                h->resident = true;
+        }
+    }
+    // iterate / residuals modes of an MFMA or wave handle run on the resident tile when one fits, else on the streaming kernel
+    if (h->use_mfma && rqp_res2_fits(h)) h->resident = true;
+    if (h->use_mfma) h->kernel_name = "mfma";
+    else if (h->use_wave) h->kernel_name = "wave";
+    else if (h->resident) h->kernel_name = "resident2";
+    return RQP_OK;
+}
+
+// pack (QP.__init__ casts) -> G = A'cA -> K_j ladder -> kernel images, for new H and/or A (NULL: keep the packed copy).
+// Shared by rqp_setup and rqp_update_mats.
+int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    HIP_TRY(h, rqp_launch_pack_mats(h, a, s));
+    HIP_TRY(h, rqp_launch_gram(h, a, s));
+    HIP_TRY(h, rqp_launch_factor(h, a, s));
+    if (h->resident) {
+        if (!h->Apack) {
+            size_t ae, ke, he;
+            rqp_res2_pack_elems(h, &ae, &ke, &he);
+            HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
+            HIP_TRY(h, rqp_prepare_res2(h));
+        }
+        HIP_TRY(h, rqp_launch_pack_res2(h, s));
+    }
+    if (h->use_mfma) {
+        if (!h->W1img) {
+            HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));
+            HIP_TRY(h, rqp_prepare_mfma(h));
+        }
+        HIP_TRY(h, rqp_launch_pack_mfma(h, s));
+    }
+    return RQP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -131,6 +222,11 @@ int rqp_default_settings(rqp_settings* s) {
     s->max_iter = 4000;
     s->check_interval = 25;
     s->warm_starting = 1;
+    s->eps_rel = 0.0;        // extensions: off = the reference's behaviour
+    s->eps_prim_inf = 1e-4;
+    s->eps_dual_inf = 1e-4;
+    s->scaling = 0;
+    s->check_infeasibility = 0;
     return RQP_OK;
 }
 
@@ -139,10 +235,20 @@ int rqp_create(rqp_handle** out, const rqp_dims* dims, const rqp_settings* setti
     *out = nullptr;
     if (dims->n < 1 || dims->m < 1 || dims->batch < 1) return RQP_ERR_ARG;
     if (dims->dtype != RQP_F32 && dims->dtype != RQP_F64) return RQP_ERR_ARG;
+    if (dims->kernel < RQP_KERNEL_AUTO || dims->kernel > RQP_KERNEL_MFMA) return RQP_ERR_ARG;
+    if (dims->tile_dtype != RQP_TILE_SAME && !(dims->tile_dtype == RQP_TILE_F16 && dims->dtype == RQP_F32)) return RQP_ERR_ARG;
     if (!settings_valid(*settings)) return RQP_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return RQP_ERR_HIP;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return RQP_ERR_HIP;
     rqp_handle* h = new rqp_handle();
+    h->ncu = pr.multiProcessorCount;
+    {   // diagnostics only (occupancy print / s_memtime build); read once, never consulted for kernel selection
+        const char* d1 = getenv("RQP_DEBUG");
+        const char* d2 = getenv("RQP_DIAG");
+        h->debug = ((d1 && d1[0] == '1') ? 1 : 0) | ((d2 && d2[0] == '1') ? 2 : 0);
+    }
     h->dims = *dims;
     h->st = *settings;
     h->device = device;
@@ -173,6 +279,22 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->device));
     free_ws(h);
+    {
+        const int rc = select_kernels(h);
+        if (rc != RQP_OK) return rc;
+    }
+    {
+        // the streaming kernel backs every handle (iterate / residuals modes, sizes beyond the tiles): its vectors must fit LDS
+        const size_t lds = rqp_generic_lds_bytes(h);
+        if (lds > 160 * 1024) {
+            char buf[256];
+            snprintf(buf, sizeof(buf), "rqp_setup: n=%d, m=%d needs %zu B of LDS for the vector state of the streaming kernel "
+                     "(limit 163840 B per workgroup)", h->n, h->m, lds);
+            h->err = buf;
+            return RQP_ERR_UNSUPPORTED;
+        }
+        HIP_TRY(h, rqp_prepare_generic(h));
+    }
     const size_t n = h->n, m = h->m, B = h->B, nm = h->nmat, e = h->esz;
     HIP_TRY(h, hipMalloc(&h->Ht, nm * n * h->ldn * e));
     HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));
@@ -194,60 +316,40 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         h->fscratch_elems = nm * h->nrho * n * n;
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
-    SetupArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n = h->n; a.m = h->m; a.ldn = h->ldn; a.ldm = h->ldm; a.nrho = h->nrho; a.B = h->B; a.nmat = h->nmat;
-    a.sigma = h->st.sigma;
-    a.eq_tol = h->st.eq_tol;
-    a.H_in = H; a.A_in = A; a.g_in = g; a.l_in = l; a.u_in = u;
-    a.Ht = h->Ht; a.A = h->A; a.At = h->At; a.K = h->K; a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
-    a.G = h->G;
-    a.rhos = h->rhos_d;
-    a.fscratch = h->fscratch;
-    HIP_TRY(h, rqp_launch_pack(h, a, s));
-    HIP_TRY(h, rqp_launch_gram(h, a, s));
-    HIP_TRY(h, rqp_launch_factor(h, a, s));
-    const char* force = getenv("RQP_FORCE_GENERIC");
-    const char* kind = getenv("RQP_RESIDENT");            // "1": first resident layout (A/B runs); default: layout 2
-    const bool want_v1 = kind && kind[0] == '1';
-    // small problems: one wavefront per instance (solve() only; iterate / residuals then run on the streaming kernel, so
-    // the resident images are not built at all)
-    const char* wv = getenv("RQP_WAVE");                  // "0": never
-    const bool want_wave = rqp_wave_fits(h) && !(force && force[0] == '1') && !(wv && wv[0] == '0') && !want_v1;
-    if (!want_wave && !(force && force[0] == '1') && (want_v1 ? rqp_resident_fits(h) : rqp_res2_fits(h))) {
-        size_t ae, ke, he;
-        if (want_v1)
-            rqp_resident_pack_elems(h, &ae, &ke, &he);
-        else
-            rqp_res2_pack_elems(h, &ae, &ke, &he);
-        HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
-        HIP_TRY(h, want_v1 ? rqp_launch_pack_resident(h, s) : rqp_launch_pack_res2(h, s));
-        h->resident = true;
-        h->res_kind = want_v1 ? 1 : 2;
-        h->kernel_name = want_v1 ? "resident" : "resident2";
+    HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
+    SetupArgs a = make_setup_args(h, H, g, A, l, u);
+    HIP_TRY(h, rqp_launch_pack_vecs(h, a, s));
+    if (h->dims.shared_mats && h->B > 1) {
+        // K is built from ONE equality pattern c (rho x 1e3 on rows with u - l <= eq_tol, reluqpth.py:54); the kernels
+        // scale rho by every instance's own c.  A shared-matrix batch must therefore share the pattern.
+        int32_t bad = 0;
+        HIP_TRY(h, rqp_launch_check_shared_c(h, h->flag_d, s));
+        HIP_TRY(h, hipMemcpyAsync(&bad, h->flag_d, sizeof(bad), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (bad) {
+            free_ws(h);
+            h->err = "rqp_setup: shared (H, A) batch whose instances differ in which rows are equalities (u - l <= eq_tol); "
+                     "K(rho) is built per matrix, so pass H and A with a batch dimension for such a batch";
+            return RQP_ERR_UNSUPPORTED;
+        }
     }
-    // shared-(H,A) batches large enough to fill the chip with 16-instance tiles go to the MFMA kernel
-    // (crossover measured on the condensed-MPC shape: 1024 -> resident 1.7x faster, 2048 -> even cold / MFMA 1.3x closed loop,
-    //  3072 -> MFMA 1.35x / 1.8x)
-    const char* mf = getenv("RQP_MFMA");                  // "0": never, "1": whenever it fits
-    // default: from ~2k instances (below, the per-instance kernels still win) and only for problems beyond the small /
-    // mid per-instance tiles -- the MFMA tile costs the same whatever the problem size (minus skipped zero groups), and
-    // on n=30, m=60 the one-wavefront kernel is 3-4x faster, on n=20, m=80 the mid resident tile is on par (measured)
-    const bool mfma_pays = h->B >= 2048 && (h->n > 56 || h->m > 128);
-    h->use_mfma = rqp_mfma_fits(h) && !(force && force[0] == '1') && !(mf && mf[0] == '0') &&
-                  (mfma_pays || (mf && mf[0] == '1'));
-    if (h->use_mfma) {
-        HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));
-        HIP_TRY(h, rqp_launch_pack_mfma(h, s));
-        h->kernel_name = "mfma";
+    int rc = build_matrices(h, a, s);
+    if (rc != RQP_OK) {
+        free_ws(h);
+        return rc;
     }
-    h->use_wave = want_wave && !h->use_mfma;
-    if (h->use_wave) h->kernel_name = "wave";
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
+}
+
+int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream) {
+    if (!h) return RQP_ERR_ARG;
+    if (!h->is_setup) return RQP_ERR_STATE;
+    if (!H && !A) return RQP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    SetupArgs a = make_setup_args(h, H, nullptr, A, nullptr, nullptr);
+    return build_matrices(h, a, s);             // state, rho indices, g, l, u, c untouched
 }
 
 int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void* stream) {
@@ -273,9 +375,15 @@ int rqp_update_settings(rqp_handle* h, const rqp_settings* s) {
     const rqp_settings& o = h->st;
     if (s->rho != o.rho || s->rho_min != o.rho_min || s->rho_max != o.rho_max || s->sigma != o.sigma ||
         s->adaptive_rho != o.adaptive_rho || s->adaptive_rho_tolerance != o.adaptive_rho_tolerance ||
-        s->eq_tol != o.eq_tol)
-        return fail_arg(h, "rqp_update_settings: only max_iter, eps_abs, check_interval, warm_starting may change");
-    if (s->max_iter < 0 || s->check_interval < 1 || s->eps_abs < 0) return fail_arg(h, "rqp_update_settings: bad value");
+        s->eq_tol != o.eq_tol || s->scaling != o.scaling)
+        return fail_arg(h, "rqp_update_settings: only max_iter, eps_abs, eps_rel, check_interval, warm_starting, "
+                           "check_infeasibility, eps_prim_inf, eps_dual_inf may change");
+    if (s->max_iter < 0 || s->check_interval < 1 || s->eps_abs < 0 || s->eps_rel < 0 || s->eps_prim_inf < 0 || s->eps_dual_inf < 0)
+        return fail_arg(h, "rqp_update_settings: bad value");
+    h->st.eps_rel = s->eps_rel;
+    h->st.check_infeasibility = s->check_infeasibility;
+    h->st.eps_prim_inf = s->eps_prim_inf;
+    h->st.eps_dual_inf = s->eps_dual_inf;
     h->st.max_iter = s->max_iter;
     h->st.eps_abs = s->eps_abs;
     h->st.check_interval = s->check_interval;

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     }
 }
 
-static size_t generic_lds_bytes(const rqp_handle* h) {
+size_t rqp_generic_lds_bytes(const rqp_handle* h) {
     const size_t W = (h->esz == 4) ? 4 : 2;
     const size_t maxd = (size_t)(h->ldn > h->ldm ? h->ldn : h->ldm);
     size_t dbl = (size_t)h->n + 3 * (size_t)h->m;
@@ -324,23 +324,19 @@ static size_t generic_lds_bytes(const rqp_handle* h) {
     return dbl * sizeof(double) + t * h->esz;
 }
 
+// once per handle (rqp_setup): raise the dynamic-LDS limit of the instantiation this handle launches
+hipError_t rqp_prepare_generic(const rqp_handle* h) {
+    const size_t lds = rqp_generic_lds_bytes(h);
+    if (lds <= 48 * 1024) return hipSuccess;
+    return h->esz == 4 ? hipFuncSetAttribute((const void*)k_admm_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipFuncSetAttribute((const void*)k_admm_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    const size_t lds = generic_lds_bytes(h);
-    hipError_t e;
-    if (h->esz == 4) {
-        if (lds > 48 * 1024) {
-            e = hipFuncSetAttribute((const void*)k_admm_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds);
-            if (e != hipSuccess) return e;
-        }
+    const size_t lds = rqp_generic_lds_bytes(h);
+    if (h->esz == 4)
         k_admm_generic<float><<<h->B, RQP_NT, lds, s>>>(a);
-    } else {
-        if (lds > 48 * 1024) {
-            e = hipFuncSetAttribute((const void*)k_admm_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds);
-            if (e != hipSuccess) return e;
-        }
+    else
         k_admm_generic<double><<<h->B, RQP_NT, lds, s>>>(a);
-    }
     return hipGetLastError();
 }

@@ -42,14 +42,17 @@ struct rqp_handle {
     double* rhos_d = nullptr;
     double* fscratch = nullptr;   // factor workspace when n*n doubles exceed LDS
     size_t fscratch_elems = 0;
-    // resident kernel images (rqp_resident.hip): lane-linear register / LDS layouts
+    // resident kernel images (rqp_resident2.hip): lane-linear register / LDS layouts
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
-    bool resident = false;
-    int res_kind = 0;             // 1: rqp_resident.hip (row-block layout), 2: rqp_resident2.hip (column block per wave)
+    bool resident = false;        // rqp_resident2.hip: A, K in VGPRs (solve, iterate and residuals modes)
     bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
+    int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
+    int ncu = 0;                  // compute units of `device` (cached at rqp_create)
+    int debug = 0;                // bit 0: RQP_DEBUG (occupancy print at setup), bit 1: RQP_DIAG (s_memtime build); read ONCE
+                                  // at rqp_create -- diagnostics only, kernel selection never depends on the environment
 
     const char* kernel_name = "generic";
     std::string err;
@@ -83,7 +86,9 @@ struct SetupArgs {
 };
 
 // launchers (defined in the .hip files); return hipError_t of the launch
-hipError_t rqp_launch_pack(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_pack_mats(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_pack_vecs(const rqp_handle* h, const SetupArgs& a, hipStream_t s);
+hipError_t rqp_launch_check_shared_c(const rqp_handle* h, int32_t* flag, hipStream_t s);
 hipError_t rqp_launch_affine_update(const rqp_handle* h, const void* p, int np, const void* Gg, const void* Glu,
                                     const void* l0, const void* u0, hipStream_t s);
 hipError_t rqp_launch_vec_update(const rqp_handle* h, const void* g, const void* l, const void* u, hipStream_t s);
@@ -95,12 +100,13 @@ hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* 
 hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
 hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
 
-// resident (register/LDS) variant, float32 only
-bool rqp_resident_fits(const rqp_handle* h);
-size_t rqp_resident_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
-hipError_t rqp_launch_pack_resident(const rqp_handle* h, hipStream_t s);
-hipError_t rqp_launch_solve_resident(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+// one-time launch preparation (dynamic-LDS function attributes), called from rqp_setup for the selected kernels
+hipError_t rqp_prepare_generic(const rqp_handle* h);
+hipError_t rqp_prepare_res2(const rqp_handle* h);
+hipError_t rqp_prepare_mfma(const rqp_handle* h);
+size_t rqp_generic_lds_bytes(const rqp_handle* h);
 
+// resident (register/LDS) variant, float32 only
 bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);

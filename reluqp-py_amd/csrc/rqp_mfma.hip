@@ -872,19 +872,20 @@ hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
     k_meta_mfma<CfgM55><<<1, 64, 0, s>>>(h->W1img, meta);
     return hipGetLastError();
 }
-hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+hipError_t rqp_prepare_mfma(const rqp_handle* h) {
     const size_t lds = CfgM55::lds_floats() * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    if (e == hipSuccess && (h->debug & 2))
+        e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e;
+}
+hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = CfgM55::lds_floats() * sizeof(float);
+    hipError_t e;
     const int tiles = (h->B + 15) / 16;
     // More tiles than CUs (one workgroup per CU: 150 KB of LDS, up to 512 registers per lane): persistent grid, slots
     // refill from a queue.  (The refill needs every exit to fall on a check, i.e. max_iter on the check grid.)
-    static int ncu = 0;
-    if (ncu == 0) {
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, h->device) != hipSuccess) return hipErrorInvalidDevice;
-        ncu = pr.multiProcessorCount;
-    }
+    const int ncu = h->ncu;
     int grid = tiles;
     int* queue = nullptr;
     if (tiles > ncu && h->queue && a.max_iter > 0 && a.check_interval > 0 && a.max_iter % a.check_interval == 0) {
@@ -893,12 +894,11 @@ hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStr
         e = hipMemsetAsync(queue, 0, sizeof(int), s);
         if (e != hipSuccess) return e;
     }
-    if (const char* dg = getenv("RQP_DIAG")) {
-        if (dg[0] == '1') {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+    {
+        if (h->debug & 2) {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
             unsigned long long* dbg = nullptr;
             const size_t cnt = (size_t)grid * 4 * 12;
             if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
-            (void)hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             k_admm_mfma<CfgM55, true><<<grid, CfgM55::NT, lds, s>>>(a, h->W1img, queue, dbg);
             (void)hipStreamSynchronize(s);
             std::vector<unsigned long long> hb(cnt);

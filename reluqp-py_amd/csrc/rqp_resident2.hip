@@ -685,45 +685,55 @@ hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
 }
 
 template <class C>
-static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+static hipError_t prepare_t(const rqp_handle* h) {
     const size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (const char* dbg = getenv("RQP_DEBUG")) {
-        if (dbg[0] == '1') {
-            int nb = -1;
-            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false>, C::NT, lds);
-            hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<C, false>);
-            fprintf(stderr, "[rqp] k_admm_res2<%d,%d,%d,%d>: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", C::RB, C::CQ,
-                    C::KR, C::KC, nb, (int)oe, lds, fa.numRegs, (size_t)fa.localSizeBytes);
-        }
+    if (h->debug & 2) e = hipFuncSetAttribute((const void*)k_admm_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (h->debug & 1) {
+        int nb = -1;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false>, C::NT, lds);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<C, false>);
+        fprintf(stderr, "[rqp] k_admm_res2<%d,%d,%d,%d>: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", C::RB, C::CQ,
+                C::KR, C::KC, nb, (int)oe, lds, fa.numRegs, (size_t)fa.localSizeBytes);
     }
-    if (const char* dg = getenv("RQP_DIAG")) {
-        if (dg[0] == '1') {      // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
-            unsigned long long* dbg = nullptr;
-            const size_t cnt = (size_t)h->B * 4 * 10;
-            if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
-            (void)hipFuncSetAttribute((const void*)k_admm_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            k_admm_res2<C, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> hbuf(cnt);
-            (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
-            (void)hipFree(dbg);
-            static const char* names[9] = {"B3 wait", "A'nu+Hx", "B1 wait", "Kd+x", "A dx", "B2 wait", "-", "rows", "check"};
-            for (int w = 0; w < 4; ++w) {
-                double tot[9] = {0}, its = 0;
-                for (int b = 0; b < h->B; ++b) {
-                    for (int e = 0; e < 9; ++e) tot[e] += (double)hbuf[((size_t)b * 4 + w) * 10 + e];
-                    its += (double)hbuf[((size_t)b * 4 + w) * 10 + 9];
-                }
-                fprintf(stderr, "[rqp diag] wave %d cycles/iteration:", w);
-                double sum = 0;
-                for (int e = 0; e < 9; ++e) { fprintf(stderr, " %s=%.0f", names[e], tot[e] / its); sum += tot[e] / its; }
-                fprintf(stderr, " | total=%.0f\n", sum);
+    return e;
+}
+hipError_t rqp_prepare_res2(const rqp_handle* h) {
+    switch (res2_pick(h)) {
+        case 0: return prepare_t<Cfg2C4>(h);
+        case 1: return prepare_t<Cfg2M>(h);
+        case 3: return prepare_t<Cfg2N>(h);
+        default: return prepare_t<Cfg2C2>(h);
+    }
+}
+
+template <class C>
+static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    const size_t lds = C::lds_bytes();
+    if (h->debug & 2) {          // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+        unsigned long long* dbg = nullptr;
+        const size_t cnt = (size_t)h->B * 4 * 10;
+        if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
+        k_admm_res2<C, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> hbuf(cnt);
+        (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        static const char* names[9] = {"B3 wait", "A'nu+Hx", "B1 wait", "Kd+x", "A dx", "B2 wait", "-", "rows", "check"};
+        for (int w = 0; w < 4; ++w) {
+            double tot[9] = {0}, its = 0;
+            for (int b = 0; b < h->B; ++b) {
+                for (int e = 0; e < 9; ++e) tot[e] += (double)hbuf[((size_t)b * 4 + w) * 10 + e];
+                its += (double)hbuf[((size_t)b * 4 + w) * 10 + 9];
             }
-            return hipGetLastError();
+            fprintf(stderr, "[rqp diag] wave %d cycles/iteration:", w);
+            double sum = 0;
+            for (int e = 0; e < 9; ++e) { fprintf(stderr, " %s=%.0f", names[e], tot[e] / its); sum += tot[e] / its; }
+            fprintf(stderr, " | total=%.0f\n", sum);
         }
+        return hipGetLastError();
     }
     k_admm_res2<C, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr);
     return hipGetLastError();

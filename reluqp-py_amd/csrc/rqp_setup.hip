@@ -11,28 +11,34 @@
 #include "rqp_common.h"
 
 // ------------------------------------------------------------------------------ pack
-// Ht[r][c] = H[c][r]; A copied with padded leading dim; At[r][c] = A[c][r]; pads zeroed.
+// Ht = sym(H) = (H + H')/2 (the quadratic form only sees the symmetric part; every kernel may then read rows of Ht as
+// rows of H, and K is built from the same matrix); A copied with padded leading dim; At[r][c] = A[c][r]; pads zeroed.
+// H_in / A_in may be NULL (rqp_update_mats): that matrix keeps its packed copy.
 template <typename T>
 __global__ void k_pack_mats(SetupArgs a) {
     const int mat = blockIdx.y;
-    const T* H = (const T*)a.H_in + (size_t)mat * a.n * a.n;
-    const T* A = (const T*)a.A_in + (size_t)mat * a.m * a.n;
-    T* Ht = (T*)a.Ht + (size_t)mat * a.n * a.ldn;
-    T* Ap = (T*)a.A + (size_t)mat * a.m * a.ldn;
-    T* At = (T*)a.At + (size_t)mat * a.n * a.ldm;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
-    for (int i = tid; i < a.n * a.ldn; i += nth) {
-        int r = i / a.ldn, c = i % a.ldn;
-        Ht[i] = (c < a.n) ? H[(size_t)c * a.n + r] : T(0);
+    if (a.H_in) {
+        const T* H = (const T*)a.H_in + (size_t)mat * a.n * a.n;
+        T* Ht = (T*)a.Ht + (size_t)mat * a.n * a.ldn;
+        for (int i = tid; i < a.n * a.ldn; i += nth) {
+            int r = i / a.ldn, c = i % a.ldn;
+            Ht[i] = (c < a.n) ? T(0.5) * (H[(size_t)c * a.n + r] + H[(size_t)r * a.n + c]) : T(0);
+        }
     }
-    for (int i = tid; i < a.m * a.ldn; i += nth) {
-        int r = i / a.ldn, c = i % a.ldn;
-        Ap[i] = (c < a.n) ? A[(size_t)r * a.n + c] : T(0);
-    }
-    for (int i = tid; i < a.n * a.ldm; i += nth) {
-        int r = i / a.ldm, c = i % a.ldm;
-        At[i] = (c < a.m) ? A[(size_t)c * a.n + r] : T(0);
+    if (a.A_in) {
+        const T* A = (const T*)a.A_in + (size_t)mat * a.m * a.n;
+        T* Ap = (T*)a.A + (size_t)mat * a.m * a.ldn;
+        T* At = (T*)a.At + (size_t)mat * a.n * a.ldm;
+        for (int i = tid; i < a.m * a.ldn; i += nth) {
+            int r = i / a.ldn, c = i % a.ldn;
+            Ap[i] = (c < a.n) ? A[(size_t)r * a.n + c] : T(0);
+        }
+        for (int i = tid; i < a.n * a.ldm; i += nth) {
+            int r = i / a.ldm, c = i % a.ldm;
+            At[i] = (c < a.m) ? A[(size_t)c * a.n + r] : T(0);
+        }
     }
 }
 
@@ -53,15 +59,41 @@ __global__ void k_pack_vecs(SetupArgs a) {
     }
 }
 
-hipError_t rqp_launch_pack(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+hipError_t rqp_launch_pack_mats(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     dim3 grid(64, h->nmat);
-    if (h->esz == 4) {
+    if (h->esz == 4)
         k_pack_mats<float><<<grid, 256, 0, s>>>(a);
-        k_pack_vecs<float><<<256, 256, 0, s>>>(a);
-    } else {
+    else
         k_pack_mats<double><<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t rqp_launch_pack_vecs(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    if (h->esz == 4)
+        k_pack_vecs<float><<<256, 256, 0, s>>>(a);
+    else
         k_pack_vecs<double><<<256, 256, 0, s>>>(a);
-    }
+    return hipGetLastError();
+}
+
+// *flag = 1 when some instance's equality scale c differs from instance 0's (shared-matrix batches: K is built from
+// instance 0's pattern, rqp_setup refuses a heterogeneous batch)
+template <typename T>
+__global__ void k_check_shared_c(int B, int m, const T* __restrict__ c, int32_t* flag) {
+    const size_t total = (size_t)B * m;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        bad |= c[i] != c[i % m];
+    if (bad) atomicOr(flag, 1);
+}
+
+hipError_t rqp_launch_check_shared_c(const rqp_handle* h, int32_t* flag, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    if (h->esz == 4)
+        k_check_shared_c<float><<<256, 256, 0, s>>>(h->B, h->m, (const float*)h->c, flag);
+    else
+        k_check_shared_c<double><<<256, 256, 0, s>>>(h->B, h->m, (const double*)h->c, flag);
     return hipGetLastError();
 }
 

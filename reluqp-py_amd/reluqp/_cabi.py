@@ -11,11 +11,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RQP_LIB", os.path.join(_HERE, "lib", "librqp_hip.so"))
 
 RQP_F32, RQP_F64 = 0, 1
-STATUS_STR = {0: "solved", 1: "max_iters_reached", -1: "unsolved"}
+RQP_TILE_SAME, RQP_TILE_F16 = 0, 1
+KERNELS = {"auto": 0, "generic": 1, "resident": 2, "resident2": 2, "wave": 3, "mfma": 4}     # enum rqp_kernel
+RQP_ERR_UNSUPPORTED = -5
+STATUS_STR = {0: "solved", 1: "max_iters_reached", 2: "nan_detected", 3: "primal_infeasible", 4: "dual_infeasible",
+              -1: "unsolved"}
 
 # every symbol include/rqp_abi.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
-    "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_affine", "rqp_update_settings",
+    "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_mats", "rqp_update_affine",
+    "rqp_update_settings",
     "rqp_warm_start", "rqp_clear_primal_dual", "rqp_solve", "rqp_iterate", "rqp_compute_residuals",
     "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
     "rqp_last_error", "rqp_version",
@@ -27,12 +32,14 @@ class RqpUnavailable(RuntimeError):
 
 
 class RqpError(RuntimeError):
-    """A C-ABI call returned a negative rqp_error."""
+    """A C-ABI call returned a negative rqp_error (``code``)."""
+    code = 0
 
 
 class Dims(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("m", ctypes.c_int32), ("batch", ctypes.c_int32),
-                ("shared_mats", ctypes.c_int32), ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("shared_mats", ctypes.c_int32), ("dtype", ctypes.c_int32), ("kernel", ctypes.c_int32),
+                ("tile_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class CSettings(ctypes.Structure):
@@ -40,7 +47,9 @@ class CSettings(ctypes.Structure):
                 ("sigma", ctypes.c_double), ("adaptive_rho_tolerance", ctypes.c_double),
                 ("eps_abs", ctypes.c_double), ("eq_tol", ctypes.c_double),
                 ("adaptive_rho", ctypes.c_int32), ("max_iter", ctypes.c_int32),
-                ("check_interval", ctypes.c_int32), ("warm_starting", ctypes.c_int32)]
+                ("check_interval", ctypes.c_int32), ("warm_starting", ctypes.c_int32),
+                ("eps_rel", ctypes.c_double), ("eps_prim_inf", ctypes.c_double), ("eps_dual_inf", ctypes.c_double),
+                ("scaling", ctypes.c_int32), ("check_infeasibility", ctypes.c_int32)]
 
 
 class CInfo(ctypes.Structure):
@@ -77,6 +86,7 @@ def load():
         "rqp_create": (ctypes.c_int, [ctypes.POINTER(H), ctypes.POINTER(Dims), ctypes.POINTER(CSettings), ctypes.c_int]),
         "rqp_setup": (ctypes.c_int, [H, vp, vp, vp, vp, vp, vp]),
         "rqp_update": (ctypes.c_int, [H, vp, vp, vp, vp]),
+        "rqp_update_mats": (ctypes.c_int, [H, vp, vp, vp]),
         "rqp_update_affine": (ctypes.c_int, [H, vp, ctypes.c_int32, vp, vp, vp, vp, vp]),
         "rqp_update_settings": (ctypes.c_int, [H, ctypes.POINTER(CSettings)]),
         "rqp_warm_start": (ctypes.c_int, [H, vp, vp, vp, ctypes.c_int, dbl, vp]),
@@ -107,7 +117,9 @@ def check(handle, rc, what):
     lib = load()
     msg = lib.rqp_strerror(rc).decode()
     detail = lib.rqp_last_error(handle).decode() if handle else ""
-    raise RqpError("%s failed: %s (%d)%s" % (what, msg, rc, (": " + detail) if detail else ""))
+    err = RqpError("%s failed: %s (%d)%s" % (what, msg, rc, (": " + detail) if detail else ""))
+    err.code = rc
+    raise err
 
 
 def ptr(t):

@@ -67,7 +67,11 @@ class Settings(object):
                  eq_tol=1e-6,
                  check_interval=25,
                  device=None,
-                 precision=torch.float64):
+                 precision=torch.float64,
+                 eps_rel=0.0,
+                 eps_prim_inf=1e-4,
+                 eps_dual_inf=1e-4,
+                 check_infeasibility=False):
         self.verbose = verbose
         self.warm_starting = warm_starting
         self.scaling = scaling
@@ -84,6 +88,11 @@ class Settings(object):
         self.check_interval = check_interval
         self.device = _default_device() if device is None else device
         self.precision = precision
+        # extensions; the defaults reproduce the reference
+        self.eps_rel = eps_rel
+        self.eps_prim_inf = eps_prim_inf
+        self.eps_dual_inf = eps_dual_inf
+        self.check_infeasibility = check_infeasibility
 
 
 class Info(object):

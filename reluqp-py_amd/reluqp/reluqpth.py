@@ -29,7 +29,7 @@ import torch
 from reluqp import _cabi
 from reluqp.classes import QP, Info, Results, Settings, _as_tensor, _default_device
 
-_CHANGEABLE = ("max_iter", "eps_abs", "verbose", "check_interval")
+_CHANGEABLE = ("max_iter", "eps_abs", "verbose", "check_interval", "eps_rel", "check_infeasibility")
 _FROZEN = ("rho", "rho_min", "rho_max", "sigma", "adaptive_rho", "adaptive_rho_interval",
            "adaptive_rho_tolerance")
 
@@ -79,7 +79,10 @@ class ReLU_QP(object):
                                adaptive_rho_tolerance=s.adaptive_rho_tolerance, eps_abs=s.eps_abs,
                                eq_tol=s.eq_tol, adaptive_rho=int(bool(s.adaptive_rho)),
                                max_iter=int(s.max_iter), check_interval=int(s.check_interval),
-                               warm_starting=int(bool(s.warm_starting)))
+                               warm_starting=int(bool(s.warm_starting)), eps_rel=float(s.eps_rel),
+                               eps_prim_inf=float(s.eps_prim_inf), eps_dual_inf=float(s.eps_dual_inf),
+                               scaling=(10 if s.scaling is True else int(s.scaling or 0)),
+                               check_infeasibility=int(bool(s.check_infeasibility)))
 
     def _to_dev(self, a, shape, name):
         t = _as_tensor(a).to(device=self.settings.device, dtype=self.settings.precision).contiguous()
@@ -102,7 +105,7 @@ class ReLU_QP(object):
     def setup(self, H, g, A, l, u,
               verbose=False,
               warm_starting=True,
-              scaling=False,  # accepted, unused -- as in the reference (Q12)
+              scaling=False,  # reference: accepted, unused TODO (reluqpth.py:105, Q12).  Here: True / k = Ruiz passes
               rho=0.1,
               rho_min=1e-6,
               rho_max=1e6,
@@ -115,7 +118,13 @@ class ReLU_QP(object):
               check_interval=25,
               device=None,
               precision=torch.float64,
-              eq_tol=1e-6):
+              eq_tol=1e-6,
+              eps_rel=0.0,
+              check_infeasibility=False,
+              eps_prim_inf=1e-4,
+              eps_dual_inf=1e-4,
+              kernel="auto",
+              iterate_dtype=None):
         """
         Setup ReLU-QP solver problem of the form
 
@@ -125,6 +134,12 @@ class ReLU_QP(object):
         solver settings can be specified as additional keyword arguments
         (reference reluqpth.py:102-157).  g, l, u may carry a leading batch
         dimension; H and A then either carry it too or are shared.
+
+        Extensions beyond the reference (all default to its behaviour): ``eps_rel``, ``scaling``,
+        ``check_infeasibility``; ``kernel`` = "auto" | "generic" | "resident" | "wave" |
+        "mfma" (C-ABI rqp_dims.kernel; an explicit kernel that cannot hold the problem raises);
+        ``iterate_dtype=torch.float16`` keeps the K(rho) tile of the register-resident kernels in fp16
+        (BASELINE config 5; H, A, state and residuals stay float32).
         """
         device = _default_device() if device is None else torch.device(device)
         if precision not in (torch.float32, torch.float64):
@@ -142,14 +157,24 @@ class ReLU_QP(object):
                                  adaptive_rho_interval=adaptive_rho_interval,
                                  adaptive_rho_tolerance=adaptive_rho_tolerance, max_iter=max_iter,
                                  eps_abs=eps_abs, eq_tol=eq_tol, check_interval=check_interval,
-                                 device=device, precision=precision)
+                                 device=device, precision=precision, eps_rel=eps_rel,
+                                 eps_prim_inf=eps_prim_inf, eps_dual_inf=eps_dual_inf,
+                                 check_infeasibility=check_infeasibility)
+        if kernel not in _cabi.KERNELS:
+            raise ValueError("kernel must be one of %s" % sorted(_cabi.KERNELS))
+        if iterate_dtype not in (None, precision, torch.float16):
+            raise ValueError("iterate_dtype must be None, the working precision or torch.float16")
+        if iterate_dtype == torch.float16 and precision != torch.float32:
+            raise ValueError("iterate_dtype=torch.float16 needs precision=torch.float32")
+        tile = _cabi.RQP_TILE_F16 if iterate_dtype == torch.float16 else _cabi.RQP_TILE_SAME
         with torch.cuda.device(device):
             start, end = self._events()
             start.record()
             self.QP = QP(H, g, A, l, u, device=device, precision=precision)
             qp = self.QP
             dims = _cabi.Dims(n=qp.nx, m=qp.nc, batch=qp.batch, shared_mats=int(qp.shared_mats),
-                              dtype=_cabi.RQP_F32 if precision == torch.float32 else _cabi.RQP_F64, reserved=0)
+                              dtype=_cabi.RQP_F32 if precision == torch.float32 else _cabi.RQP_F64,
+                              kernel=_cabi.KERNELS[kernel], tile_dtype=tile, reserved=0)
             cs = self._csettings()
             h = ctypes.c_void_p()
             _cabi.check(None, lib.rqp_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(cs), device.index),
@@ -176,14 +201,24 @@ class ReLU_QP(object):
         Update ReLU-QP problem arguments (reference reluqpth.py:159-183; numpy or torch, Q9)
         """
         self._need_setup()
-        # assert that matrices cannot be changed for now (reluqpth.py:177)
-        assert Hx is None and Ax is None, "updating Hx and Ax is not supported yet"
         lib = _cabi.load()
         qp = self.QP
         lead = (qp.batch,) if qp.batched else ()
         with torch.cuda.device(self.settings.device):
             start, end = self._events()
             start.record()
+            # The reference asserts here (`updating Hx and Ax is not supported yet`, reluqpth.py:176-177).  SURVEY.md
+            # 8(f)-4: Hx / Ax are the new dense H / A (same shapes as at setup); the device re-runs the setup chain
+            # (C-ABI rqp_update_mats) and keeps the ADMM state, so the next solve() is warm-started.
+            if Hx is not None or Ax is not None:
+                matlead = (qp.batch,) if (qp.batched and not qp.shared_mats) else ()
+                if Hx is not None:
+                    qp.H = self._to_dev(Hx, matlead + (qp.nx, qp.nx), "Hx")
+                if Ax is not None:
+                    qp.A = self._to_dev(Ax, matlead + (qp.nc, qp.nx), "Ax")
+                _cabi.check(self._h, lib.rqp_update_mats(self._h, _cabi.ptr(qp.H if Hx is not None else None),
+                                                         _cabi.ptr(qp.A if Ax is not None else None), self._stream()),
+                            "rqp_update_mats")
             if g is not None:
                 qp.g = self._to_dev(g, lead + (qp.nx,), "g")
             if l is not None:

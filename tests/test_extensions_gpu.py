@@ -1,0 +1,239 @@
+"""GPU tests of the rows SURVEY.md 8(f) marks "next" and of the round-1 ADVICE items, through the C-ABI:
+
+  f2  benchmarks/random_qps.py harness (reference random_qps.py:47-81) with the oracle as the cross-solver check
+  f4  update(Hx=, Ax=)  (rejected upstream, reluqpth.py:176-177) against an oracle re-setup with the carried state
+  shared-matrix batches with heterogeneous equality rows are refused (K is built per matrix)
+  non-symmetric H is symmetrised once at pack time: every kernel solves the same problem
+  adaptive_rho=False still checks convergence (Q3 fixed) -- iteration count / status pinned against the oracle
+  fixed-k parity (rqp_iterate / rqp_compute_residuals) of the big resident tile
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reluqp_oracle as O
+from reluqp import _cabi, utils
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _np(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _solver(H, g, A, l, u, **kw):
+    import reluqp.reluqpth as reluqpth
+    m = reluqpth.ReLU_QP()
+    m.setup(H, g, A, l, u, device=DEV, **kw)
+    return m
+
+
+# ------------------------------------------------------------------------------------------ f2
+def test_random_qps_harness_vs_oracle():
+    """The reference's benchmark loop (rand_qp(nx, nx/4, nx/4), status must be "solved", float64, tol 1e-4) with the
+    oracle (tight tolerance, float64) standing in for the OSQP agreement check of random_qps.py:68."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rqp_bench_random_qps",
+                                                  os.path.join(here, "reluqp-py_amd", "benchmarks", "random_qps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    checked = []
+
+    def check(nx, seed, tol, x):
+        H, g, A, l, u, _ = utils.rand_qp(nx=nx, n_eq=nx // 4, n_ineq=nx // 4, seed=seed, compute_sol=False)
+        qp = O.OracleQP(form="factored")
+        qp.setup(H, g, A, l, u, eps_abs=1e-9, max_iter=20000)
+        r = qp.solve()
+        assert r.info.status == "solved"
+        assert np.linalg.norm(_np(x) - r.x, ord=np.inf) < 10 * tol           # random_qps.py:68 with the oracle as "OSQP"
+        checked.append((nx, seed))
+
+    bench = mod.Random_QP_benchmark(precision=torch.float64)
+    rows = bench.random_initial_solve(nx_min=10, nx_max=100, n_sample=4, n_seeds=3, tol=1e-4, check=check)
+    assert [r["nx"] for r in rows] == [10, 21, 46, 100] and len(checked) == 12
+    assert all(r["reluqpth_mean_s"] > 0 for r in rows)
+    # float32 column (the MI355X default precision) on the same sweep
+    bench32 = mod.Random_QP_benchmark(precision=torch.float32)
+    rows32 = bench32.random_initial_solve(nx_min=10, nx_max=100, n_sample=4, n_seeds=3, tol=1e-4, check=check)
+    assert len(rows32) == 4
+    # the batched extension: all seeds of one size in ONE call
+    out = bench.batched_solve(46, 64, tol=1e-4)
+    assert out["solved_frac"] == 1.0
+
+
+# ------------------------------------------------------------------------------------------ f4
+@pytest.mark.parametrize("prec,tol", [(torch.float64, 1e-7), (torch.float32, 5e-5)])
+@pytest.mark.parametrize("n,n_eq,n_ineq,B", [(10, 3, 12, 6), (100, 25, 275, 4)])
+def test_update_matrices_vs_oracle(prec, tol, n, n_eq, n_ineq, B):
+    """update(Hx=, Ax=): pack -> gram -> factor -> kernel images re-run on the device, state kept.  The oracle defines the
+    semantics (the reference asserts): new matrices, K ladder rebuilt with the equality pattern of setup, carried state."""
+    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=40, feasible=True)
+    rs = np.random.RandomState(1)
+    M = 0.1 * rs.randn(B, n, n)
+    H2 = H + np.einsum("bij,bkj->bik", M, M)                        # still SPD
+    A2 = A + 0.05 * rs.randn(*A.shape)
+    m = _solver(H, g, A, l, u, precision=prec)
+    r0 = m.solve()
+    assert all(s == "solved" for s in r0.info.status)
+    m.update(Hx=H2)                                                  # H only
+    r1 = m.solve()
+    m.update(Ax=A2)                                                  # then A only
+    r2 = m.solve()
+    m.update(Hx=H, Ax=A)                                             # both, back to the original
+    r3 = m.solve()
+    refs = []
+    for b in range(B):
+        qp = O.OracleQP(form="factored")
+        qp.setup(H[b], g[b], A[b], l[b], u[b])
+        a0 = qp.solve()
+        qp.update(Hx=H2[b])
+        a1 = qp.solve()
+        a1 = (a1.x.copy(), a1.info.iter, a1.info.status)
+        qp.update(Ax=A2[b])
+        a2 = qp.solve()
+        a2 = (a2.x.copy(), a2.info.iter, a2.info.status)
+        qp.update(Hx=H[b], Ax=A[b])
+        a3 = qp.solve()
+        refs.append((a1, a2, (a3.x.copy(), a3.info.iter, a3.info.status)))
+    for k, r in enumerate((r1, r2, r3)):
+        it = r.info.iter.cpu().numpy()
+        it_ref = np.array([refs[b][k][1] for b in range(B)])
+        x_ref = np.stack([refs[b][k][0] for b in range(B)])
+        assert list(r.info.status) == [refs[b][k][2] for b in range(B)]
+        if prec == torch.float64:
+            assert np.array_equal(it, it_ref)
+        else:
+            assert np.all(np.abs(it - it_ref) <= 25)
+        same = it == it_ref
+        np.testing.assert_allclose(_np(r.x)[same], x_ref[same], rtol=0, atol=tol * max(1.0, np.abs(x_ref).max()))
+    # warm start pays: the re-solves after a small matrix change are not slower than the cold solve
+    assert float(r1.info.iter.double().mean()) <= float(r0.info.iter.double().mean())
+    with pytest.raises(ValueError):
+        m.update(Hx=np.eye(n + 1))
+
+
+def test_update_matrices_shared_batch_mfma_and_wave():
+    """Shared (H, A): one matrix update serves the whole batch; the MFMA images and the resident images are re-packed."""
+    from reluqp import mpc
+    Ad, Bd = mpc.random_plant(6, 2, seed=7)
+    ctl = mpc.LinearMPC(Ad, Bd, np.eye(6), 0.1 * np.eye(2), 10, 0.4, 8.0, form="condensed")
+    x0 = 1.5 * np.random.RandomState(7).randn(48, 6)
+    g, l, u = ctl.qp_vectors(x0)
+    H2 = ctl.H + 0.3 * np.eye(ctl.H.shape[0])
+    ref = O.solve_batch(H2, g, ctl.A, l, u, form="factored", eps_abs=1e-3)
+    for kern in ("mfma", "auto", "resident", "generic"):
+        m = _solver(ctl.H, g, ctl.A, l, u, precision=torch.float32, kernel=kern, warm_starting=False)
+        m.solve()
+        m.update(Hx=H2)
+        r = m.solve()                                                # cold (warm_starting=False): comparable with a fresh oracle
+        it = r.info.iter.cpu().numpy()
+        assert list(r.info.status) == ref["status"], kern
+        assert np.mean(it == ref["iter"]) >= 0.85, kern
+        same = it == ref["iter"]
+        np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0, atol=1e-4 * max(1.0, np.abs(ref["x"]).max()))
+
+
+# ------------------------------------------------------------------- ADVICE: shared c pattern
+def test_shared_matrices_heterogeneous_equality_rows_refused():
+    n, m_, B = 8, 12, 5
+    rs = np.random.RandomState(0)
+    M = rs.randn(n, n)
+    H, A = M.T @ M + np.eye(n), rs.randn(m_, n)
+    g = rs.randn(B, n)
+    l = -np.ones((B, m_))
+    u = np.ones((B, m_))
+    l[3, 2] = u[3, 2] = 0.25                                         # instance 3 alone has row 2 as an equality
+    import reluqp.reluqpth as reluqpth
+    mdl = reluqpth.ReLU_QP()
+    with pytest.raises(_cabi.RqpError) as ei:
+        mdl.setup(H, g, A, l, u, device=DEV, precision=torch.float32)
+    assert ei.value.code == _cabi.RQP_ERR_UNSUPPORTED and "equalit" in str(ei.value)
+    # batched matrices carry a K per instance: accepted, and equal to the oracle
+    Hb, Ab = np.broadcast_to(H, (B, n, n)).copy(), np.broadcast_to(A, (B, m_, n)).copy()
+    mdl.setup(Hb, g, Ab, l, u, device=DEV, precision=torch.float64)
+    r = mdl.solve()
+    ref = O.solve_batch(Hb, g, Ab, l, u, form="factored")
+    assert np.array_equal(r.info.iter.cpu().numpy(), ref["iter"])
+    np.testing.assert_allclose(_np(r.x), ref["x"], rtol=1e-6, atol=1e-7)
+    # a homogeneous pattern (same equality rows everywhere) is fine when shared
+    l[:, 2] = u[:, 2] = 0.25
+    mdl.setup(H, g, A, l, u, device=DEV, precision=torch.float32)
+    assert all(s == "solved" for s in mdl.solve().info.status)
+
+
+# ------------------------------------------------------------------- ADVICE: non-symmetric H
+@pytest.mark.parametrize("n,m_,kernels", [(12, 20, ("generic", "wave", "resident")), (60, 100, ("generic", "resident"))])
+def test_nonsymmetric_H_is_symmetrised(n, m_, kernels):
+    """x'Hx only sees sym(H) = (H + H')/2: the pack kernel stores sym(H), so every kernel (whatever the dispatch picks)
+    and the oracle on sym(H) agree.  (The reference would iterate with the raw H: not a QP gradient.)"""
+    rs = np.random.RandomState(2)
+    B = 4
+    M = rs.randn(n, n)
+    Hs = M.T @ M + np.eye(n)
+    N = rs.randn(n, n)
+    H = Hs + 0.3 * (N - N.T)                                         # same symmetric part, non-symmetric matrix
+    A = rs.randn(m_, n)
+    g = rs.randn(B, n)
+    l, u = -np.ones((B, m_)), np.ones((B, m_))
+    ref = O.solve_batch(Hs, g, A, l, u, form="factored")
+    for kern in kernels:
+        for shared in (True, False):
+            Hin = H if shared else np.broadcast_to(H, (B, n, n)).copy()
+            Ain = A if shared else np.broadcast_to(A, (B, m_, n)).copy()
+            m = _solver(Hin, g, Ain, l, u, precision=torch.float32, kernel=kern)
+            r = m.solve()
+            it = r.info.iter.cpu().numpy()
+            assert np.all(np.abs(it - ref["iter"]) <= 25), kern
+            same = it == ref["iter"]
+            assert same.sum() >= B - 1
+            np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0, atol=5e-5 * max(1.0, np.abs(ref["x"]).max()))
+            np.testing.assert_allclose(_np(r.info.obj_val)[same], ref["obj_val"][same], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------- ADVICE: adaptive_rho=False
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+def test_adaptive_rho_false_checks_convergence(golden, prec):
+    """Q3 (deliberate deviation): with adaptive_rho=False the reference never checks convergence (reluqpth.py:218) and
+    returns its initial zero x after max_iter iterations; the build checks every check_interval iterations on the single
+    rho of the ladder.  Pinned against the oracle with the same fix (quirks=False) and contrasted with quirks=True."""
+    g3 = golden("g3_c1_feasible.npz")
+    H, g, A, l, u = (g3["s0_" + k] for k in ("H", "g", "A", "l", "u"))
+    ref = O.OracleQP(form="factored", quirks=False)
+    ref.setup(H, g, A, l, u, adaptive_rho=False, rho=1.0)
+    rr = ref.solve()
+    m = _solver(H, g, A, l, u, precision=prec, adaptive_rho=False, rho=1.0)
+    r = m.solve()
+    assert len(m.layers.rhos) == 1 and r.info.rho_ind == 0
+    assert r.info.status == rr.info.status == "solved"
+    assert r.info.iter == rr.info.iter and r.info.iter < 4000
+    np.testing.assert_allclose(_np(r.x), rr.x, rtol=0, atol=(1e-8 if prec == torch.float64 else 2e-5) * max(1.0, np.abs(rr.x).max()))
+    quirk = O.OracleQP(form="factored", quirks=True)
+    quirk.setup(H, g, A, l, u, adaptive_rho=False, rho=1.0, max_iter=200)
+    rq = quirk.solve()
+    assert rq.info.status == "max_iters_reached" and rq.info.iter == 200      # what the reference does
+
+
+# ------------------------------------------------------------------- big resident tile, fixed k
+def test_resident_big_tile_fixed_k_and_residuals_vs_oracle():
+    """rqp_iterate / rqp_compute_residuals (modes 1 / 2 of k_admm_res2) on the n <= 104, m <= 320 tile against the
+    oracle's fixed-k states (forward, reluqpth.py:80-89) and compute_residuals (:307-318) at n=100, m=300."""
+    H, g, A, l, u, _ = utils.rand_qp(nx=100, n_eq=25, n_ineq=275, seed=1, feasible=True)
+    qp = O.OracleQP(form="factored")
+    qp.setup(H, g, A, l, u)
+    m = _solver(H, g, A, l, u, precision=torch.float32, kernel="resident")
+    assert m.kernel == "resident2"
+    for k in (1, 4, 20):
+        s_ref = qp.iterate(k).copy()
+        s = _np(m.iterate(k))
+        np.testing.assert_allclose(s, s_ref, rtol=0, atol=5e-5 * max(1.0, np.abs(s_ref).max()))
+    n, mm = 100, 300
+    x, z, lam = s_ref[:n], s_ref[n:n + mm], s_ref[n + mm:]
+    pri, dua, rho = O.compute_residuals(H, A, g, x, z, lam, 0.7, 1e-6, 1e6)
+    p, d, r, J = [float(v) for v in m.compute_residuals(0.7)]
+    np.testing.assert_allclose(p, pri, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(d, dua, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(r, rho, rtol=5e-3)
+    np.testing.assert_allclose(J, O.compute_J(H, g, x), rtol=1e-4)

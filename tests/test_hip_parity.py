@@ -28,25 +28,26 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _model(H, g, A, l, u, precision=torch.float64, generic=False, wave=True, **kw):
-    """generic=True forces the streaming kernel (k_admm_generic) where a resident one would fit; wave=False keeps small
-    problems off the one-wavefront-per-instance kernel (they then run on the small resident tile)."""
-    import os
+def _model(H, g, A, l, u, precision=torch.float64, generic=False, wave=True, kernel=None, **kw):
+    """generic=True requests the streaming kernel (k_admm_generic) where a resident one would fit; wave=False keeps small
+    problems off the one-wavefront-per-instance kernel (they then run on the resident tile, or stream in float64).
+    The request travels through the C ABI (rqp_dims.kernel), not through the environment."""
     import reluqp.reluqpth as reluqpth
     m = reluqpth.ReLU_QP()
     m.collect_trace = True
-    os.environ["RQP_FORCE_GENERIC"] = "1" if generic else "0"
-    os.environ["RQP_WAVE"] = "1" if wave else "0"
-    try:
-        m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, **kw)
-    finally:
-        os.environ["RQP_FORCE_GENERIC"] = "0"
-        os.environ.pop("RQP_WAVE", None)
+    n_, m_ = np.shape(H)[-1], np.shape(A)[-2]
+    if kernel is None:
+        kernel = "auto"
+        if generic:
+            kernel = "generic"
+        elif not wave:
+            kernel = "resident" if (precision == torch.float32 and n_ <= 104 and m_ <= 320) else "generic"
+    m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, kernel=kernel, **kw)
     if generic:
         assert m.kernel == "generic"
-    elif precision == torch.float64:            # float64: the one-wavefront kernel for small problems, else streaming
-        small = H.shape[-1] <= 32 and A.shape[-2] <= 64
-        assert m.kernel == ("wave" if (small and wave) else "generic")
+    elif precision == torch.float64 and kernel == "auto":   # float64: the one-wavefront kernel for small problems, else streaming
+        small = n_ <= 32 and m_ <= 64
+        assert m.kernel == ("wave" if small else "generic")
     return m
 
 
@@ -96,7 +97,7 @@ def test_g1_ladder_and_kernel_loaded(golden):
     m = _model(*_qp(g))
     assert np.array_equal(_np(m.layers.rhos), g["rhos"])
     assert m.rho_ind == int(g["rho_ind0"]) == 7
-    assert m.kernel in ("generic", "resident", "resident2", "wave")
+    assert m.kernel in ("generic", "resident2", "wave")
     m2 = _model(*_qp(g), adaptive_rho=False)
     assert np.array_equal(_np(m2.layers.rhos), g["rhos_noadapt"])
     m3 = _model(*_qp(g), rho=0.4, rho_min=1e-3, rho_max=1e3, adaptive_rho_tolerance=3)
@@ -104,15 +105,21 @@ def test_g1_ladder_and_kernel_loaded(golden):
     assert m3.rho_ind == int(g["rho_ind0_alt"])
 
 
-@pytest.mark.parametrize("prec,xtol,rr,ra", PREC)
-def test_g1_iterates(golden, prec, xtol, rr, ra):
+# (precision, tolerances..., kernel request): rqp_iterate / rqp_compute_residuals (modes 1 / 2) run on the streaming kernel
+# for a wave handle and on k_admm_res2 for a resident handle -- both meet the reference's fixed-k states
+PREC_K = [p + ("auto",) for p in PREC] + [PREC[1] + ("resident",)]
+
+
+@pytest.mark.parametrize("prec,xtol,rr,ra,kern", PREC_K)
+def test_g1_iterates(golden, prec, xtol, rr, ra, kern):
     g = golden("g1_builtin.npz")
     for k, key in ((1, "state_k1"), (2, "state_k2"), (25, "state_k25")):
-        m = _model(*_qp(g), precision=prec)
+        m = _model(*_qp(g), precision=prec, kernel=kern)
+        assert kern == "auto" or m.kernel == "resident2"
         s = m.iterate(k)
         np.testing.assert_allclose(_np(s), g[key], rtol=0, atol=xtol * 10 * max(1, np.abs(g[key]).max()))
     # k iterations in two calls == one call (state round-trips through HBM in float64)
-    m = _model(*_qp(g), precision=prec)
+    m = _model(*_qp(g), precision=prec, kernel=kern)
     m.iterate(10)
     s = m.iterate(15)
     np.testing.assert_allclose(_np(s), g["state_k25"], rtol=0, atol=xtol * 10 * 5)
@@ -230,19 +237,20 @@ def test_g5_update(golden, prec, xtol, rr, ra):
     res = m.solve()
     _check_vs_gold(g, "upd_lu_", m, res, xtol, check_rho=False)
     assert res.info.solve_time >= res.info.run_time > 0
-    with pytest.raises(AssertionError):
-        m.update(Hx=np.eye(3))                                     # reluqpth.py:177
+    with pytest.raises(ValueError):
+        m.update(Hx=np.eye(4))                                     # wrong shape (the reference asserts on ANY Hx, reluqpth.py:177)
 
 
 # --------------------------------------------- G6: compute_residuals / compute_J
-@pytest.mark.parametrize("prec,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
-def test_g6_residuals(golden, prec, rtol):
+@pytest.mark.parametrize("prec,rtol,kern", [(torch.float64, 1e-9, "auto"), (torch.float32, 2e-4, "auto"),
+                                            (torch.float32, 2e-4, "resident")])
+def test_g6_residuals(golden, prec, rtol, kern):
     g = golden("g6_residuals.npz")
     for i in range(int(g["n_cases"])):
         p = "c%d_" % i
         H, A, gg = g[p + "H"], g[p + "A"], g[p + "g"]
         mm = A.shape[0]
-        m = _model(H, gg, A, np.full(mm, -np.inf), np.full(mm, np.inf), precision=prec)
+        m = _model(H, gg, A, np.full(mm, -np.inf), np.full(mm, np.inf), precision=prec, kernel=kern)
         m.warm_start(x=g[p + "x"], z=g[p + "z"], lam=g[p + "lam"])
         pri, dua, rho, J = [float(v) for v in m.compute_residuals(float(g[p + "rho_in"]))]
         floor = 1e-12 if prec == torch.float64 else 1e-5         # cancellation floor of O(1..10) sums
@@ -490,7 +498,7 @@ def test_cabi_error_paths_on_device():
     dev = _dev()
     s = _cabi.CSettings()
     lib.rqp_default_settings(ctypes.byref(s))
-    d = _cabi.Dims(n=4, m=6, batch=2, shared_mats=0, dtype=0, reserved=0)
+    d = _cabi.Dims(n=4, m=6, batch=2, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, reserved=0)
     h = ctypes.c_void_p()
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(d), ctypes.byref(s), dev.index or 0) == 0
     try:

@@ -57,23 +57,15 @@ def test_mpc_closed_loop_update_and_warm_start():
 def test_mfma_kernel_matches_resident_and_oracle(B):
     """Shared-(H,A) batches on the MFMA kernel (forced with RQP_MFMA=1): same exits as the per-instance resident
     kernel and the oracle, x within float32 tolerance; ragged last tile (B=40 = 2.5 tiles)."""
-    import os
     import reluqp.reluqpth as reluqpth
     ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=11, B=B)
     g, l, u = ctl.qp_vectors(x0)
     dev = torch.device("cuda:0")
-    os.environ["RQP_MFMA"] = "1"
-    try:
-        mm = reluqpth.ReLU_QP()
-        mm.collect_trace = True
-        mm.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3)
-    finally:
-        os.environ["RQP_MFMA"] = "0"
-    try:
-        mr = reluqpth.ReLU_QP()
-        mr.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3)
-    finally:
-        del os.environ["RQP_MFMA"]
+    mm = reluqpth.ReLU_QP()
+    mm.collect_trace = True
+    mm.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3, kernel="mfma")
+    mr = reluqpth.ReLU_QP()
+    mr.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32, eps_abs=1e-3)
     assert mm.kernel == "mfma" and mr.kernel in ("resident2", "wave")
     rm, rr = mm.solve(), mr.solve()
     ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", eps_abs=1e-3)
@@ -97,22 +89,15 @@ def test_mfma_kernel_matches_resident_and_oracle(B):
 
 
 def _solve_with_env(val, ctl, g, l, u, **settings):
-    """setup()+solve() with RQP_MFMA set to `val` (None: unset, i.e. the default dispatch) around setup()."""
-    import os
+    """setup()+solve() with a kernel request through the C ABI: "1" -> the MFMA kernel, "0" -> a per-instance kernel
+    (the resident tile where the default dispatch would pick MFMA), None -> the default dispatch."""
     import reluqp.reluqpth as reluqpth
-    old = os.environ.get("RQP_MFMA")
-    if val is None:
-        os.environ.pop("RQP_MFMA", None)
-    else:
-        os.environ["RQP_MFMA"] = val
-    try:
-        m = reluqpth.ReLU_QP()
-        m.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, **settings)
-    finally:
-        if old is None:
-            os.environ.pop("RQP_MFMA", None)
-        else:
-            os.environ["RQP_MFMA"] = old
+    n_, m_ = ctl.H.shape[-1], ctl.A.shape[-2]
+    kernel = {"1": "mfma", None: "auto"}.get(val)
+    if kernel is None:
+        kernel = "resident" if (g.shape[0] >= 2048 and (n_ > 56 or m_ > 128)) else "auto"
+    m = reluqpth.ReLU_QP()
+    m.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, kernel=kernel, **settings)
     return m, m.solve()
 
 

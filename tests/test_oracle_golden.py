@@ -221,8 +221,19 @@ def test_g5_update(golden, form):
     qp.update(l=g["l_new"], u=g["u_new"])
     res = qp.solve()
     _check_result(g, "upd_lu_", qp, res, 1e-7, atol=1e-9)
+    qq = O.OracleQP(form=form, quirks=True)                       # the reference's behaviour (reluqpth.py:176-177)
+    qq.setup(H, gg, A, l, u)
     with pytest.raises(AssertionError):
-        qp.update(Hx=np.eye(3))                                    # reluqpth.py:177
+        qq.update(Hx=np.eye(3))
+    # the build's definition: same as a fresh setup with the new matrices and the carried state
+    H2 = H + 0.5 * np.eye(3)
+    qp.update(Hx=H2)
+    res = qp.solve()
+    fresh = O.OracleQP(form=form)
+    fresh.setup(H2, g["g_new"], A, g["l_new"], g["u_new"])
+    rf = fresh.solve()
+    assert res.info.status == rf.info.status == "solved"
+    np.testing.assert_allclose(res.x, rf.x, atol=5e-3)             # both within eps_abs of the same optimum
 
 
 # ------------------------------------------------ G6: compute_residuals / compute_J

@@ -11,10 +11,9 @@ for (nx, nu, N) in [(2, 2, 15), (4, 2, 8), (6, 2, 10)]:
     for B in (4096, 65536):
         x0 = np.random.RandomState(3).randn(B, nx)
         g, l, u = ctl.qp_vectors(x0)
-        for env in ("1", "0"):
-            os.environ["RQP_MFMA"] = env
+        for kern in ("mfma", "auto"):
             m = reluqpth.ReLU_QP()
-            m.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, warm_starting=False)
+            m.setup(ctl.H, g, ctl.A, l, u, device=torch.device("cuda:0"), precision=torch.float32, warm_starting=False, kernel=kern)
             m.solve(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(5):

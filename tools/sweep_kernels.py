@@ -14,18 +14,9 @@ import reluqp.reluqpth as reluqpth  # noqa: E402
 from reluqp import mpc, utils  # noqa: E402
 
 
-def solve(H, g, A, l, u, prec, env, **kw):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        m = reluqpth.ReLU_QP()
-        m.setup(H, g, A, l, u, device=torch.device("cuda:0"), precision=prec, **kw)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def solve(H, g, A, l, u, prec, kernel, **kw):
+    m = reluqpth.ReLU_QP()
+    m.setup(H, g, A, l, u, device=torch.device("cuda:0"), precision=prec, kernel=kernel, **kw)
     return m, m.solve()
 
 
@@ -56,8 +47,8 @@ def main():
         prec = torch.float32 if (rs.rand() < 0.6 or m > 64 or n > 32) else torch.float64
         eps = float(rs.choice([1e-3, 1e-4]))
         H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, m - n_eq, seed0=1000 * case, feasible=True)
-        mw, rw = solve(H, g, A, l, u, prec, {"RQP_FORCE_GENERIC": "0"}, eps_abs=eps)
-        mg, rg = solve(H, g, A, l, u, prec, {"RQP_FORCE_GENERIC": "1"}, eps_abs=eps)
+        mw, rw = solve(H, g, A, l, u, prec, "auto", eps_abs=eps)
+        mg, rg = solve(H, g, A, l, u, prec, "generic", eps_abs=eps)
         assert mw.kernel == "wave" and mg.kernel == "generic", (mw.kernel, mg.kernel)
         bad += not compare("wave    n=%d m=%d (eq %d) B=%d %s eps %g" % (n, m, n_eq, B, str(prec)[6:], eps), rw, rg, prec)
     for case in range(max(4, ncase // 3)):
@@ -75,8 +66,8 @@ def main():
             continue
         x0 = rs.randn(B, nx)
         g, l, u = ctl.qp_vectors(x0)
-        mm, rm = solve(ctl.H, g, ctl.A, l, u, torch.float32, {"RQP_MFMA": "1"}, eps_abs=1e-3)
-        mr, rr = solve(ctl.H, g, ctl.A, l, u, torch.float32, {"RQP_MFMA": "0"}, eps_abs=1e-3)
+        mm, rm = solve(ctl.H, g, ctl.A, l, u, torch.float32, "mfma", eps_abs=1e-3)
+        mr, rr = solve(ctl.H, g, ctl.A, l, u, torch.float32, "resident", eps_abs=1e-3)
         assert mm.kernel == "mfma", mm.kernel
         bad += not compare("mfma    nx=%d nu=%d N=%d (n=%d m=%d) B=%d vs %s" % (nx, nu, N, N * nu, N * (nx + nu), B, mr.kernel), rm, rr, torch.float32)
     print("failures:", bad)
