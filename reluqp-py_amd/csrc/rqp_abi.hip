@@ -72,7 +72,7 @@ int argmin_abs(const std::vector<double>& r, double v) {   // np.argmin(np.abs(r
 void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
-                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->W1img, (void**)&h->queue,
+                     (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
                      (void**)&h->flag_d};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -135,7 +135,12 @@ SetupArgs make_setup_args(const rqp_handle* h, const void* H, const void* g, con
 
 // Kernel selection (rqp_dims.kernel; AUTO = measured crossovers).  Pure function of the handle: no environment.
 int select_kernels(rqp_handle* h) {
-    const int req = h->dims.kernel;
+    int req = h->dims.kernel;
+    if (h->dims.tile_dtype == RQP_TILE_F16) {     // the fp16 K tile lives in the register-resident kernel
+        if (req == RQP_KERNEL_AUTO && rqp_res2_fits(h)) req = RQP_KERNEL_RESIDENT;
+        if (req != RQP_KERNEL_RESIDENT)
+            return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320)");
+    }
     h->resident = h->use_wave = h->use_mfma = false;
     h->kernel_name = "generic";
     switch (req) {
@@ -171,6 +176,7 @@ int select_kernels(rqp_handle* h) {
     }
     // iterate / residuals modes of an MFMA or wave handle run on the resident tile when one fits, else on the streaming kernel
     if (h->use_mfma && rqp_res2_fits(h)) h->resident = true;
+    if (h->dims.tile_dtype == RQP_TILE_F16 && !h->resident) return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel");
     if (h->use_mfma) h->kernel_name = "mfma";
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
@@ -190,6 +196,7 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
             HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
             HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
+            if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
             HIP_TRY(h, rqp_prepare_res2(h));
         }
         HIP_TRY(h, rqp_launch_pack_res2(h, s));

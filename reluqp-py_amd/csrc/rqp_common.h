@@ -44,6 +44,7 @@ struct rqp_handle {
     size_t fscratch_elems = 0;
     // resident kernel images (rqp_resident2.hip): lane-linear register / LDS layouts
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
+    float* Kscale = nullptr;      // [nmat][nrho] power-of-two scale of the fp16 K tile (tile_dtype = RQP_TILE_F16)
     bool resident = false;        // rqp_resident2.hip: A, K in VGPRs (solve, iterate and residuals modes)
     bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only

@@ -25,7 +25,18 @@
 #include "rqp_common.h"
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// acc + float(half of k) * v in one v_fma_mix_f32 (op_sel picks the low / high half of the dword; float32 multiply-add).
+// Inline asm: left to the compiler the conversion is hoisted out of the solve loop and K sits in registers as float32 again.
+__device__ __forceinline__ float fma_mix_lo(h2 k, float v, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(k), "v"(v));
+    return acc;
+}
+__device__ __forceinline__ float fma_mix_hi(h2 k, float v, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(k), "v"(v));
+    return acc;
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp2(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -103,10 +114,14 @@ struct Res2Cfg {
 
 // DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles wave 0 spends
 // in each segment of the iteration into `dbg` (never read by the kernel; never timed as the product).
-template <class C, bool DIAG>
+// KH = true: the K(rho) tile is stored as fp16 row pairs (rqp_dims.tile_dtype = RQP_TILE_F16, BASELINE config 5): half the
+// registers and half the reload bytes; products accumulate in float32 (v_fma_mix_f32 reads the half operand directly), the
+// per-(matrix, rho) power-of-two scale Kscale keeps the entries inside the fp16 range.  K only preconditions dx = -K d.
+template <class C, bool DIAG, bool KH>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs a, const float* __restrict__ Apack,
                                                       const float* __restrict__ Kpack,
-                                                      const float* __restrict__ Hpack, unsigned long long* dbg) {
+                                                      const float* __restrict__ Hpack, unsigned long long* dbg,
+                                                      const float* __restrict__ Kscale) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, NW = C::NW, RP = C::RP, KP = C::KP;
     constexpr int CW = C::CW, M = C::M, ND = C::ND, SW = C::SW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HP = C::HP, HR = C::HR, H1 = C::H1, H2 = C::H2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -152,13 +167,16 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         for (int u = 0; u < HU; ++u) ((float4*)Hs)[u * NT + tid] = Hp[u * NT + tid];
     }
     int ri = a.rho_ind[b];
-    f2 kr[KP][KC];
+    typedef typename std::conditional<KH, h2, f2>::type kpair_t;      // a row pair of K: two floats, or two halves in one dword
+    kpair_t kr[KP][KC];
+    float kscale = 1.f;
     auto load_K = [&](int j) {
-        const f2* Kp = (const f2*)(Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT * 2) + tid;
+        const kpair_t* Kp = (const kpair_t*)Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT + tid;
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
             for (int c = 0; c < KC; ++c) kr[kp][c] = Kp[(size_t)(kp * KC + c) * NT];
+        if constexpr (KH) kscale = Kscale[mat * a.nrho + j];
     };
     load_K(ri);
 
@@ -309,8 +327,18 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             f2 t = {0.f, 0.f};
+            if constexpr (KH) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) t = __builtin_elementwise_fma(kr[kp][c], (f2){vc[c], vc[c]}, t);
+                for (int c = 0; c < KC; ++c) {                       // v_fma_mix_f32: fp16 operand, float32 multiply-add
+                    t.x = fma_mix_lo(kr[kp][c], vc[c], t.x);
+                    t.y = fma_mix_hi(kr[kp][c], vc[c], t.y);
+                }
+                t.x *= kscale;
+                t.y *= kscale;
+            } else {
+#pragma unroll
+                for (int c = 0; c < KC; ++c) t = __builtin_elementwise_fma(kr[kp][c], (f2){vc[c], vc[c]}, t);
+            }
             s[2 * kp] = t.x;
             s[2 * kp + 1] = t.y;
         }
@@ -599,10 +627,11 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 //   Apack[mat][pair = rp*CQ + c][t][2]      = A[RB*pl + 2rp + h][CW*w + CQ*q + c]
 //   Kpack[mat][j][pair = kp*KC + c][t][2]   = K_j[CW*w + KR*rr + 2kp + h][KC*cc + c]   (0 when KR*rr + 2kp + h >= CW)
 //   Hpack[mat][c][t][4]                     = H[HR*pl + 0..3][CW*w + CQ*q + c]
-template <class C>
+//   KH: Kpack holds fp16 pairs (one dword per row pair) of K_j / Kscale[mat][j], Kscale = 2^e with max|K_j| / Kscale <= 2^14
+template <class C, bool KH>
 __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
-                            float* __restrict__ Hpack) {
+                            float* __restrict__ Hpack, float* __restrict__ Kscale) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR;
     const int mat = blockIdx.y;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -626,12 +655,33 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
     } else {
         const int j = blockIdx.x - 1;
         const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
-        float* Kp = Kpack + ((size_t)mat * nrho + j) * KE2 * NT * 2;
+        float inv_scale = 1.f;
+        if constexpr (KH) {                                          // block max |K_j| -> power-of-two scale
+            __shared__ float smax[NT];
+            float mx = 0.f;
+            for (int i = t; i < n * ldn; i += NT) mx = fmaxf(mx, fabsf(Kj[i]));
+            smax[t] = mx;
+            __syncthreads();
+            for (int off = NT / 2; off >= 1; off >>= 1) {
+                if (t < off) smax[t] = fmaxf(smax[t], smax[t + off]);
+                __syncthreads();
+            }
+            int e2 = 0;
+            (void)frexpf(fmaxf(smax[0], 1e-30f), &e2);               // max = f * 2^e2, f in [0.5, 1)
+            const float sc = ldexpf(1.f, e2 - 14);
+            inv_scale = ldexpf(1.f, 14 - e2);
+            if (t == 0) Kscale[(size_t)mat * nrho + j] = sc;
+        }
+        float* Kp = Kpack + ((size_t)mat * nrho + j) * KE2 * NT * (KH ? 1 : 2);
         for (int e = 0; e < KE2 * 2; ++e) {
             const int pair = e >> 1, h = e & 1;
             const int lr = KR * rr + 2 * (pair / KC) + h;
             const int r = CW * w + lr, c = KC * cc + pair % KC;
-            Kp[((size_t)pair * NT + t) * 2 + h] = (lr < CW && r < n && c < n) ? Kj[(size_t)r * ldn + c] : 0.f;
+            const float v = (lr < CW && r < n && c < n) ? Kj[(size_t)r * ldn + c] : 0.f;
+            if constexpr (KH)
+                ((_Float16*)Kp)[((size_t)pair * NT + t) * 2 + h] = (_Float16)(v * inv_scale);
+            else
+                Kp[((size_t)pair * NT + t) * 2 + h] = v;
         }
     }
 }
@@ -656,7 +706,7 @@ bool rqp_res2_fits(const rqp_handle* h) { return res2_pick(h) >= 0; }
 template <class C>
 static void pack_elems_t(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
     *a_elems = (size_t)h->nmat * C::AE2 * C::NT * 2;
-    *k_elems = (size_t)h->nmat * h->nrho * C::KE2 * C::NT * 2;
+    *k_elems = (size_t)h->nmat * h->nrho * C::KE2 * C::NT * (h->dims.tile_dtype == RQP_TILE_F16 ? 1 : 2);
     *h_elems = (size_t)h->nmat * C::HU * C::NT * 4;
 }
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
@@ -671,8 +721,12 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
 template <class C>
 static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
     dim3 grid(1 + h->nrho, h->nmat);
-    k_pack_res2<C><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
-                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack);
+    if (h->dims.tile_dtype == RQP_TILE_F16)
+        k_pack_res2<C, true><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+                                                    (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
+    else
+        k_pack_res2<C, false><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+                                                     (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
     return hipGetLastError();
 }
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
@@ -687,14 +741,16 @@ hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
 template <class C>
 static hipError_t prepare_t(const rqp_handle* h) {
     const size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (h->dims.tile_dtype == RQP_TILE_F16)
+        return hipFuncSetAttribute((const void*)k_admm_res2<C, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (h->debug & 2) e = hipFuncSetAttribute((const void*)k_admm_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (h->debug & 2) e = hipFuncSetAttribute((const void*)k_admm_res2<C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (h->debug & 1) {
         int nb = -1;
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false>, C::NT, lds);
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false, false>, C::NT, lds);
         hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<C, false>);
+        (void)hipFuncGetAttributes(&fa, (const void*)k_admm_res2<C, false, false>);
         fprintf(stderr, "[rqp] k_admm_res2<%d,%d,%d,%d>: blocks/CU=%d (err %d) lds=%zu B regs=%d scratch=%zu B\n", C::RB, C::CQ,
                 C::KR, C::KC, nb, (int)oe, lds, fa.numRegs, (size_t)fa.localSizeBytes);
     }
@@ -712,11 +768,15 @@ hipError_t rqp_prepare_res2(const rqp_handle* h) {
 template <class C>
 static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
     const size_t lds = C::lds_bytes();
+    if (h->dims.tile_dtype == RQP_TILE_F16) {
+        k_admm_res2<C, false, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr, h->Kscale);
+        return hipGetLastError();
+    }
     if (h->debug & 2) {          // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
         unsigned long long* dbg = nullptr;
         const size_t cnt = (size_t)h->B * 4 * 10;
         if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
-        k_admm_res2<C, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg);
+        k_admm_res2<C, true, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, dbg, nullptr);
         (void)hipStreamSynchronize(s);
         std::vector<unsigned long long> hbuf(cnt);
         (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -735,7 +795,7 @@ static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s
         }
         return hipGetLastError();
     }
-    k_admm_res2<C, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr);
+    k_admm_res2<C, false, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
     return hipGetLastError();
 }
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

@@ -143,18 +143,21 @@ def _oracle_closed_loop(ctl, x0, steps):
     return np.stack(xs), its
 
 
-@pytest.mark.parametrize("tile", [None, torch.float16])
-def test_c5_closed_loop_1000_steps_vs_oracle(tile):
+@pytest.mark.parametrize("B,tile,kernel", [(4096, None, "mfma"), (64, None, "resident2"), (64, torch.float16, "resident2")])
+def test_c5_closed_loop_1000_steps_vs_oracle(B, tile, kernel):
     """1000 control steps, update(g,l,u) from the current state + warm-started solve() per step (the path of
-    reluqpth.py:159-183 + :201-249), batch 4096 at the C3 shape; instances 0..7 against the oracle closed loop.
-    tile=float16: BASELINE config 5's "fp16 iterate / fp32 residual" mode (K(rho) tile in fp16)."""
+    reluqpth.py:159-183 + :201-249) at the C3 shape; instances 0..7 against the oracle closed loop.  Batch 4096 runs on
+    the MFMA kernel, the small batch ("1 instance stream or small batch") on the register-resident tile.
+    tile=float16: BASELINE config 5's "fp16 iterate / fp32 residual" mode -- the K(rho) tile in fp16 (it only
+    preconditions dx = -K d), H, A, the state and every residual in float32/float64."""
     import reluqp.reluqpth as reluqpth
-    B, NB, STEPS = 4096, 8, 1000
+    NB, STEPS = 8, 1000
     ctl, x0 = _c3(B, seed=11)
     x0 = 1.5 * x0
     g, l, u = ctl.qp_vectors(x0)
     m = reluqpth.ReLU_QP()
     m.setup(ctl.H, g, ctl.A, l, u, device=DEV, precision=torch.float32, eps_abs=1e-3, iterate_dtype=tile)
+    assert m.kernel == kernel
     mp = ctl._device_maps(DEV, torch.float32)
     x = torch.as_tensor(x0, device=DEV, dtype=torch.float32)
     m.synchronous = False                                             # enqueue only; the steps chain on the stream

@@ -237,3 +237,50 @@ def test_resident_big_tile_fixed_k_and_residuals_vs_oracle():
     np.testing.assert_allclose(d, dua, rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(r, rho, rtol=5e-3)
     np.testing.assert_allclose(J, O.compute_J(H, g, x), rtol=1e-4)
+
+
+# ------------------------------------------------------------------- fp16 K tile (BASELINE config 5)
+@pytest.mark.parametrize("shape", ["c3", "dense"])
+def test_fp16_tile_same_exits_as_float32(shape):
+    """iterate_dtype=float16 (C-ABI rqp_dims.tile_dtype = RQP_TILE_F16): K(rho) stored as fp16 in the resident kernel.
+    K only preconditions the residual correction, so the fixed point is the float32 one: every instance solved, the
+    same iteration counts on >= 85 % of the batch (stated tolerance; fp16 rounding of K shifts marginal checks), x within
+    eps_abs-level of the float32-tile run where the exits agree, KKT residuals re-derived in float64 under the thresholds."""
+    import reluqp.reluqpth as reluqpth
+    if shape == "c3":
+        from reluqp import mpc
+        Ad, Bd = mpc.random_plant(12, 4, seed=0)
+        ctl = mpc.LinearMPC(Ad, Bd, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
+        x0 = np.random.RandomState(3).randn(96, 12)
+        g, l, u = ctl.qp_vectors(x0)
+        H, A = ctl.H, ctl.A
+    else:
+        H, g, A, l, u, _ = utils.rand_qp_batch(48, 100, 25, 275, seed0=500, feasible=True)
+    out = {}
+    for tile in (None, torch.float16):
+        m = reluqpth.ReLU_QP()
+        m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, eps_abs=1e-3, iterate_dtype=tile, kernel="resident")
+        assert m.kernel == "resident2"
+        out[tile] = m.solve()
+    r32, r16 = out[None], out[torch.float16]
+    assert all(s == "solved" for s in r16.info.status) and all(s == "solved" for s in r32.info.status)
+    i32, i16 = r32.info.iter.cpu().numpy(), r16.info.iter.cpu().numpy()
+    assert np.mean(i32 == i16) >= 0.85 and np.all(np.abs(i32 - i16) <= 50)
+    same = i32 == i16
+    scale = max(1.0, float(r32.x.abs().max()))
+    np.testing.assert_allclose(_np(r16.x)[same], _np(r32.x)[same], rtol=0, atol=2e-3 * scale)
+    Hd, Ad_, gd = (torch.as_tensor(t, device=DEV, dtype=torch.float64) for t in (H, A, g))
+    x, z, y = r16.x.double(), r16.z.double(), r16.y.double()
+    if Hd.dim() == 2:
+        pri, dua = (x @ Ad_.T - z).abs().amax(1), (x @ Hd.T + y @ Ad_ + gd).abs().amax(1)
+    else:
+        pri = (torch.einsum("bmn,bn->bm", Ad_, x) - z).abs().amax(1)
+        dua = (torch.einsum("bij,bj->bi", Hd, x) + torch.einsum("bmn,bm->bn", Ad_, y) + gd).abs().amax(1)
+    mm, nn = A.shape[-2], H.shape[-1]
+    assert float(pri.max()) < 1e-3 * np.sqrt(mm) * 1.02 and float(dua.max()) < 1e-3 * np.sqrt(nn) * 1.05
+    # the tile request is refused where no kernel implements it (nothing falls back silently)
+    with pytest.raises(_cabi.RqpError) as ei:
+        reluqpth.ReLU_QP().setup(H, g, A, l, u, device=DEV, precision=torch.float32, iterate_dtype=torch.float16, kernel="generic")
+    assert ei.value.code == _cabi.RQP_ERR_UNSUPPORTED
+    with pytest.raises(ValueError):
+        reluqpth.ReLU_QP().setup(H, g, A, l, u, device=DEV, precision=torch.float64, iterate_dtype=torch.float16)
