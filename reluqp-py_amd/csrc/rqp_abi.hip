@@ -73,12 +73,13 @@ void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
                      (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
-                     (void**)&h->flag_d};
+                     (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     h->is_setup = false;
+    h->order_valid = false;
     h->resident = false;
     h->use_mfma = false;
     h->use_wave = false;
@@ -324,6 +325,10 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
+    if (!h->use_mfma && h->B >= 4 * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
+        HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));
+    }
     SetupArgs a = make_setup_args(h, H, g, A, l, u);
     HIP_TRY(h, rqp_launch_pack_vecs(h, a, s));
     if (h->dims.shared_mats && h->B > 1) {
@@ -429,7 +434,15 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     a.out_x = x; a.out_z = z; a.out_lam = lam;
     if (info) a.info = *info;
     if (a.info.trace && a.info.trace_cap < 1) return fail_arg(h, "rqp_solve: trace without capacity");
+    if (h->order_d) {
+        a.order = h->order_valid ? h->order_d : nullptr;
+        a.last_iter = h->last_iter_d;
+    }
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
+    if (h->order_d) {                               // rank the instances by what they just needed: next launch goes longest-first
+        HIP_TRY(h, rqp_launch_order_lpt(h, (hipStream_t)stream));
+        h->order_valid = true;
+    }
     return RQP_OK;
 }
 

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int W = VecT<T>::W;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;   // dispatch order: longest solve first
     const int maxd = max(ldn, ldm);
 
     // ---- LDS carve-up (host computes the same size: rqp_launch_solve_generic)
@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     if (a.out_lam) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_lam)[(size_t)b * m + i] = (T)ls[i];
     if (tid == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;

@@ -51,6 +51,13 @@ struct rqp_handle {
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
     int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
+    // Dispatch order of the per-instance kernels.  Workgroups are issued in grid order and an instance runs as long as its
+    // iteration count, so the launch ends with a tail of late, long solves (14 % of the headline launch, measured).  After
+    // every solve the instances are ranked by the iteration count they just needed (counting sort on the device) and the next
+    // launch issues them longest-first.  Pure scheduling: results do not depend on it.  Batches of >= 4 workgroups per CU only.
+    int32_t* order_d = nullptr;   // [B] instance of workgroup i
+    int32_t* last_iter_d = nullptr;
+    bool order_valid = false;
     int ncu = 0;                  // compute units of `device` (cached at rqp_create)
     int debug = 0;                // bit 0: RQP_DEBUG (occupancy print at setup), bit 1: RQP_DIAG (s_memtime build); read ONCE
                                   // at rqp_create -- diagnostics only, kernel selection never depends on the environment
@@ -73,6 +80,8 @@ struct SolveArgs {
     int32_t* rho_ind;
     void *out_x, *out_z, *out_lam;
     rqp_info info;
+    const int32_t* order;     // workgroup -> instance (NULL: identity)
+    int32_t* last_iter;       // iteration count of this solve, for the next launch's order (NULL: not recorded)
     double *r_pri, *r_dua, *r_rho, *r_obj;   // mode 2 outputs
 };
 
@@ -99,6 +108,7 @@ hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hip
 hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* z, const void* lam, int set_rho,
                                 int rho_ind, hipStream_t s);
 hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
+hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
 
 // one-time launch preparation (dynamic-LDS function attributes), called from rqp_setup for the selected kernels

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
                   "H image must start 16-byte aligned");
 
     const int n = a.n, m = a.m;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;   // dispatch order: longest solve first
     const int wave = tid >> 6, lane = tid & 63;
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
     const size_t mat = (a.sA == 0) ? 0 : (size_t)b;
@@ -359,32 +359,54 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     // interleaved, instead of two passes back to back -- wave 0 was 520 cycles behind the others at the next barrier.
     auto row_body = [&](auto nr, bool init, bool do_a, bool do_b) __attribute__((always_inline)) {
         constexpr int R = decltype(nr)::value;
-        double zt[R], z[R], lmv[R];
-        float adx[R];
+        // every LDS operand of the pass is requested up front (one latency, not one per dependent step: left to itself the
+        // compiler interleaves reads and waits -- five serial LDS round trips in the one-row path), then the float64 chain
+        double zt[R], z[R], lmv[R], iv[R];
+        float adx[R][NW], lo[R], hi[R], rvf[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const int i = tid + q * NT;
             zt[q] = zt64[i];
-            z[q] = z64[i];
             lmv[q] = lam64[i];
-            if (init || do_a) adx[q] = ((part[i] + part[M + i]) + part[2 * M + i]) + part[3 * M + i];
+            if (do_a) {
+                iv[q] = inv64[i];
+                lo[q] = lT[i];
+                hi[q] = uT[i];
+            } else {
+                z[q] = z64[i];
+            }
+            rvf[q] = rv32[i];                                          // (unconditional: do_b is a run-time flag at one call site)
+            if (init || do_a) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) adx[q][w] = part[w * M + i];
+            }
+        }
+        // one wait for all of them; the empty-asm operand lists pin every request above it and every use below it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            asm volatile("" : "+v"(zt[q]), "+v"(lmv[q]), "+v"(rvf[q]));
+            if (do_a) asm volatile("" : "+v"(iv[q]), "+v"(lo[q]), "+v"(hi[q]));
+            else asm volatile("" : "+v"(z[q]));
+            if (init || do_a) asm volatile("" : "+v"(adx[q][0]), "+v"(adx[q][1]), "+v"(adx[q][2]), "+v"(adx[q][3]));
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const int i = tid + q * NT;
             if (init || do_a) {
-                zt[q] = (init ? 0.0 : zt[q]) + (double)adx[q];
+                const float ad = ((adx[q][0] + adx[q][1]) + adx[q][2]) + adx[q][3];
+                zt[q] = (init ? 0.0 : zt[q]) + (double)ad;
                 zt64[i] = zt[q];
             }
             if (do_a) {
-                const double v = zt[q] + lmv[q] * inv64[i];
+                const double v = zt[q] + lmv[q] * iv[q];
                 z[q] = v;                                              // torch.clamp: NaN stays NaN
-                if (v < (double)lT[i]) z[q] = (double)lT[i];
-                if (v > (double)uT[i]) z[q] = (double)uT[i];
+                if (v < (double)lo[q]) z[q] = (double)lo[q];
+                if (v > (double)hi[q]) z[q] = (double)hi[q];
                 z64[i] = z[q];
             }
             if (do_b) {
-                const double rv = (double)rv32[i];
+                const double rv = (double)rvf[q];
                 const double pr = zt[q] - z[q];
                 const double lh = lmv[q] + rv * pr;
                 lam64[i] = lh;
@@ -489,6 +511,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     };
 
     stamp(-1);
+    int to_chk = a.check_interval;                                     // iterations until k % check_interval == 0
     for (int k = 1; k <= kmax; ++k) {
         __syncthreads();                                               // B3: nu (and hg) visible
         stamp(0);
@@ -498,15 +521,18 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         stamp(2);
         {
             float s[KR];
+            static_assert(KR == 4 || KR == 2, "vectorised x update");
+            const int j = SW * wave + KR * rr;
+            double2* xp = (double2*)(x64 + j);
+            double2 xold[KR / 2];                                      // x of this lane's slots: requested before the products
+#pragma unroll
+            for (int hlf = 0; hlf < KR / 2; ++hlf) xold[hlf] = xp[hlf];
             prod_K(dvec, s);                                           // K d
             if (cc == 0) {                 // this lane owns slots j..j+3 (rows >= CW of the group: zero rows of K, padding slots)
-                static_assert(KR == 4 || KR == 2, "vectorised x update");
-                const int j = SW * wave + KR * rr;
-                double2* xp = (double2*)(x64 + j);
                 f2* xn2 = (f2*)(xnat + CW * wave + KR * rr);                   // natural order: real columns only
 #pragma unroll
                 for (int hlf = 0; hlf < KR / 2; ++hlf) {
-                    double2 xa = xp[hlf];
+                    double2 xa = xold[hlf];
                     const f2 dx = {-s[2 * hlf], -s[2 * hlf + 1]};
                     xa.x += (double)dx.x;
                     xa.y += (double)dx.y;
@@ -527,7 +553,9 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         stamp(5);
         stamp(6);
         iters = k;
-        const bool check = (a.mode == 0) && ((k % a.check_interval) == 0);    // reluqpth.py:218 (Q3 fixed)
+        const bool on_grid = (--to_chk == 0);
+        if (on_grid) to_chk = a.check_interval;
+        const bool check = (a.mode == 0) && on_grid;                   // k % check_interval == 0: reluqpth.py:218 (Q3 fixed)
         if (!check) {
             row_pass(false, true, k < kmax);
             stamp(7);
@@ -598,6 +626,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     if (a.out_lam) for (int i = tid; i < m; i += NT) ((float*)a.out_lam)[(size_t)b * m + i] = (float)lam64[i];
     if (tid == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;

@@ -518,6 +518,43 @@ hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam
     return hipGetLastError();
 }
 
+// order[] = instances sorted by descending last_iter (counting sort, one workgroup; ties in arrival order of the atomics --
+// the order only schedules workgroups, results do not depend on it)
+__global__ void __launch_bounds__(1024) k_order_lpt(int B, const int32_t* __restrict__ last_iter, int32_t* __restrict__ order) {
+    constexpr int NBK = 4096;
+    __shared__ int hist[NBK];                     // indexed by NBK-1 - min(iter, NBK-1): ascending index = descending iterations
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    for (int i = t; i < NBK; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) atomicAdd(&hist[NBK - 1 - min(max(last_iter[i], 0), NBK - 1)], 1);
+    __syncthreads();
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        loc[j] = sum;
+        sum += hist[4 * t + j];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {    // inclusive Hillis-Steele scan of the 1024 partial sums
+        const int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int excl = part[t] - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hist[4 * t + j] = excl + loc[j];
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[NBK - 1 - min(max(last_iter[i], 0), NBK - 1)], 1)] = i;
+}
+
+hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s) {
+    k_order_lpt<<<1, 1024, 0, s>>>(h->B, h->last_iter_d, h->order_d);
+    return hipGetLastError();
+}
+
 template <typename T>
 __global__ void k_get_K(int n, int ldn, const T* K, T* out) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += gridDim.x * blockDim.x)

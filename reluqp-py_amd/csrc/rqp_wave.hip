@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     __shared__ __attribute__((aligned(16))) T dL[NCT];                 // d by column
     __shared__ __attribute__((aligned(16))) T dxL[NCT];                // dx by column
     __shared__ T redL[NWV][8];                                         // cross-wave maxima / sums (NWV > 1)
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x & 63;   // dispatch order: longest solve first
     const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
     const int c = NC * wv + lane % NC, h = lane / NC;                  // global column, column part
@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     if (a.out_x && h == 0 && cok) ((T*)a.out_x)[(size_t)b * n + c] = (T)x;
     if (threadIdx.x == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
