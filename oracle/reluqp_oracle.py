@@ -37,6 +37,10 @@ import numpy as np
 
 STATUS_SOLVED = "solved"
 STATUS_MAX_ITER = "max_iters_reached"
+# extensions of the build (not in the reference): SURVEY.md section 5 / 8(f)-3
+STATUS_NAN = "nan_detected"
+STATUS_PRIMAL_INFEASIBLE = "primal_infeasible"
+STATUS_DUAL_INFEASIBLE = "dual_infeasible"
 
 
 # --------------------------------------------------------------------------- a2
@@ -46,7 +50,8 @@ class Settings:
     def __init__(self, verbose=False, warm_starting=True, scaling=False, rho=0.1,
                  rho_min=1e-6, rho_max=1e6, sigma=1e-6, adaptive_rho=True,
                  adaptive_rho_interval=1, adaptive_rho_tolerance=5, max_iter=4000,
-                 eps_abs=1e-3, eq_tol=1e-6, check_interval=25, dtype=np.float64):
+                 eps_abs=1e-3, eq_tol=1e-6, check_interval=25, dtype=np.float64,
+                 eps_rel=0.0, check_infeasibility=False, eps_prim_inf=1e-4, eps_dual_inf=1e-4):
         self.verbose = verbose
         self.warm_starting = warm_starting
         self.scaling = scaling
@@ -62,6 +67,11 @@ class Settings:
         self.eq_tol = eq_tol
         self.check_interval = check_interval
         self.dtype = dtype
+        # extensions of the build, absent from the reference; the defaults are the reference's behaviour
+        self.eps_rel = eps_rel
+        self.check_infeasibility = check_infeasibility
+        self.eps_prim_inf = eps_prim_inf
+        self.eps_dual_inf = eps_dual_inf
 
 
 # --------------------------------------------------------------------------- a3
@@ -197,6 +207,15 @@ def _tmax(a, b):
     if np.isnan(a) or np.isnan(b):
         return type(a)(np.nan)
     return a if a >= b else b
+
+
+def residual_scales(H, A, g, x, z, lam):
+    """(max(|Ax|,|z|), max(|Hx|,|A'lam|,|g|)) in inf-norms: the denominators of reluqpth.py:315-316, reused by the
+    build's eps_rel extension as the scales of the two residuals."""
+    T = x.dtype.type
+    sp = _tmax(T(_inf_norm(A @ x)), T(_inf_norm(z)))
+    sd = _tmax(_tmax(T(_inf_norm(H @ x)), T(_inf_norm(A.T @ lam))), T(_inf_norm(g)))
+    return sp, sd
 
 
 def compute_residuals(H, A, g, x, z, lam, rho, rho_min, rho_max):
@@ -429,7 +448,11 @@ class OracleQP:
                     self.rho_ind -= 1
                 if st.verbose:
                     print('Iter: {}, rho: {:.2e}, res_p: {:.2e}, res_d: {:.2e}'.format(k, rho, pri, dua))
-                if pri < thr_p and dua < thr_d:            # :233
+                tp, td = thr_p, thr_d
+                if st.eps_rel > 0:                         # build extension (8(f)-3): OSQP-style relative term
+                    sp, sd = residual_scales(self.H, self.A, self.g, self.x, self.z, self.lam)
+                    tp, td = thr_p + st.eps_rel * sp, thr_d + st.eps_rel * sd
+                if pri < tp and dua < td:                  # :233
                     self._update_results(k, STATUS_SOLVED, pri, dua, rho, t0)
                     return self.results
         if not self.quirks:                                # Q11 fix: re-slice
@@ -437,7 +460,10 @@ class OracleQP:
             self.x, self.z, self.lam = s[:n], s[n:n + m], s[n + m:]
         pri, dua, rho = compute_residuals(self.H, self.A, self.g, self.x, self.z, self.lam,
                                           rho, st.rho_min, st.rho_max)           # :243
-        self._update_results(st.max_iter, STATUS_MAX_ITER, pri, dua, rho, t0)
+        status = STATUS_MAX_ITER
+        if not self.quirks and (np.isnan(pri) or np.isnan(dua)):
+            status = STATUS_NAN                            # build extension: the reference reports max_iters_reached (Q17)
+        self._update_results(st.max_iter, status, pri, dua, rho, t0)
         return self.results
 
     # a9 ------------------------------------------------------ update_results

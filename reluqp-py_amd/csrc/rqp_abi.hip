@@ -73,7 +73,8 @@ void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
                      (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
-                     (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d};
+                     (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d,
+                     (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -107,6 +108,7 @@ SolveArgs make_solve_args(const rqp_handle* h) {
     a.rho_max = h->st.rho_max;
     a.thr_p = h->st.eps_abs * std::sqrt((double)h->m);   // reluqpth.py:233
     a.thr_d = h->st.eps_abs * std::sqrt((double)h->n);
+    a.eps_rel = h->st.eps_rel;
     a.Ht = h->Ht; a.A = h->A; a.At = h->At; a.K = h->K;
     const bool sh = h->dims.shared_mats != 0;
     a.sH = sh ? 0 : (size_t)h->n * h->ldn;
@@ -188,6 +190,7 @@ int select_kernels(rqp_handle* h) {
 // Shared by rqp_setup and rqp_update_mats.
 int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     HIP_TRY(h, rqp_launch_pack_mats(h, a, s));
+    if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_ruiz(h, s));       // Ht, A, At scaled in place; D, E, c kept for the boundary
     HIP_TRY(h, rqp_launch_gram(h, a, s));
     HIP_TRY(h, rqp_launch_factor(h, a, s));
     if (h->resident) {
@@ -345,11 +348,17 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
             return RQP_ERR_UNSUPPORTED;
         }
     }
+    if (h->st.scaling > 0) {
+        HIP_TRY(h, hipMalloc((void**)&h->Dsc, nm * n * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->Esc, nm * m * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->csc, nm * sizeof(double)));
+    }
     int rc = build_matrices(h, a, s);
     if (rc != RQP_OK) {
         free_ws(h);
         return rc;
     }
+    if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_scale_vecs(h, h->g, h->l, h->u, s));    // g <- c D g, l/u <- E l/u
     h->is_setup = true;
     return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
 }
@@ -358,6 +367,9 @@ int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream) {
     if (!h) return RQP_ERR_ARG;
     if (!h->is_setup) return RQP_ERR_STATE;
     if (!H && !A) return RQP_OK;
+    if (h->st.scaling > 0)
+        return fail_unsupported(h, "rqp_update_mats with scaling: new matrices change D, E -- run rqp_setup again (state can be carried with "
+                                   "rqp_get_state / rqp_warm_start)");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->device));
     SetupArgs a = make_setup_args(h, H, nullptr, A, nullptr, nullptr);
@@ -370,6 +382,8 @@ int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void*
     if (!g && !l && !u) return RQP_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, rqp_launch_vec_update(h, g, l, u, (hipStream_t)stream));
+    if (h->st.scaling > 0)
+        HIP_TRY(h, rqp_launch_scale_vecs(h, g ? h->g : nullptr, l ? h->l : nullptr, u ? h->u : nullptr, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -379,6 +393,7 @@ int rqp_update_affine(rqp_handle* h, const void* p, int32_t np, const void* Gg, 
     if (!h->is_setup) return RQP_ERR_STATE;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, rqp_launch_affine_update(h, p, np, Gg, Glu, l0, u0, (hipStream_t)stream));
+    if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_scale_vecs(h, h->g, h->l, h->u, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -410,6 +425,8 @@ int rqp_warm_start(rqp_handle* h, const void* x, const void* z, const void* lam,
     HIP_TRY(h, hipSetDevice(h->device));
     const int ri = has_rho ? argmin_abs(h->rhos, rho) : 0;          // reluqpth.py:273-274
     HIP_TRY(h, rqp_launch_state_set(h, x, z, lam, has_rho, ri, (hipStream_t)stream));
+    if (h->st.scaling > 0 && (x || z || lam))      // caller space -> scaled space
+        HIP_TRY(h, rqp_launch_scale_state(h, x ? h->x : nullptr, z ? h->z : nullptr, lam ? h->lam : nullptr, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -443,6 +460,8 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         HIP_TRY(h, rqp_launch_order_lpt(h, (hipStream_t)stream));
         h->order_valid = true;
     }
+    if (h->st.scaling > 0)                          // x = D xb, z = zb / E, lam = E lamb / c, obj / c
+        HIP_TRY(h, rqp_launch_unscale_out(h, x, z, lam, a.info.obj_val, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -467,6 +486,7 @@ int rqp_compute_residuals(rqp_handle* h, double rho_in, double* pri, double* dua
     a.rho_in = rho_in;
     a.r_pri = pri; a.r_dua = dua; a.r_rho = rho_out; a.r_obj = obj;
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
+    if (h->st.scaling > 0 && obj) HIP_TRY(h, rqp_launch_unscale_out(h, nullptr, nullptr, nullptr, obj, (hipStream_t)stream));
     return RQP_OK;
 }
 
@@ -475,6 +495,7 @@ int rqp_get_state(rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, 
     if (!h->is_setup) return RQP_ERR_STATE;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, rqp_launch_state_get(h, x, z, lam, rho_ind, (hipStream_t)stream));
+    if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_unscale_out(h, x, z, lam, nullptr, (hipStream_t)stream));
     return RQP_OK;
 }
 

@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
 
     // ---- residuals of the current state (compute_residuals, reluqpth.py:307-318) ----------
     // leaves H x in hx (hx_valid), returns pri/dua and the new carried rho estimate
+    T scl_p = T(0), scl_d = T(0);          // max(|Ax|,|z|) and max(|Hx|,|A'lam|,|g|) of the last check (eps_rel)
     auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
         for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
         __syncthreads();
@@ -187,8 +188,10 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
         block_max<T, 7>(v, red);
         o_pri = v[0];
         o_dua = v[3];
-        const T num = v[0] / tmax(v[1], v[2]);                      // :315
-        const T den = v[3] / tmax(tmax(v[4], v[5]), v[6]);          // :316
+        scl_p = tmax(v[1], v[2]);
+        scl_d = tmax(tmax(v[4], v[5]), v[6]);
+        const T num = v[0] / scl_p;                                 // :315
+        const T den = v[3] / scl_d;                                 // :316
         T est = rho_carry * (T)sqrt(num / den);                    // :317
         if (est < (T)a.rho_min) est = (T)a.rho_min;                // torch.clamp: NaN stays NaN
         if (est > (T)a.rho_max) est = (T)a.rho_max;
@@ -250,7 +253,10 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
                 for (int i = tid; i < m; i += RQP_NT) rvT[i] = (T)a.rhos[ri] * cT[i];
                 __syncthreads();
             }
-            if (pri < (T)a.thr_p && dua < (T)a.thr_d) {            // :233
+            // :233, plus the OSQP-style relative term when eps_rel > 0 (0 = the reference's test)
+            const T tp = a.eps_rel > 0 ? (T)a.thr_p + (T)a.eps_rel * scl_p : (T)a.thr_p;
+            const T td = a.eps_rel > 0 ? (T)a.thr_d + (T)a.eps_rel * scl_d : (T)a.thr_d;
+            if (pri < tp && dua < td) {
                 converged = true;
                 break;
             }
@@ -293,7 +299,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     if (tid == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
-        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
         if (a.info.dua_res) a.info.dua_res[b] = (double)dua;

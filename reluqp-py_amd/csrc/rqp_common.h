@@ -37,6 +37,7 @@ struct rqp_handle {
     void *Ht = nullptr, *A = nullptr, *At = nullptr, *K = nullptr;
     void *g = nullptr, *l = nullptr, *u = nullptr, *c = nullptr;
     double* G = nullptr;
+    double *Dsc = nullptr, *Esc = nullptr, *csc = nullptr;   // Ruiz scaling (settings.scaling > 0): D [nmat][n], E [nmat][m], c [nmat]
     double *x = nullptr, *z = nullptr, *lam = nullptr;
     int32_t* rho_ind = nullptr;
     double* rhos_d = nullptr;
@@ -72,6 +73,7 @@ struct SolveArgs {
     int max_iter, check_interval, warm_starting, rho_ind0;
     int mode;                 // 0 solve, 1 iterate-only (k = max_iter), 2 residuals-only
     double sigma, tol, rho_min, rho_max, thr_p, thr_d, rho_in;
+    double eps_rel;           // 0: absolute test only (reluqpth.py:233); > 0: thresholds grow by eps_rel * the residual's scale
     const void *Ht, *A, *At, *K;
     size_t sH, sA, sAt, sK;   // per-instance strides in elements (0 when shared)
     const void *g, *l, *u, *c;
@@ -108,6 +110,10 @@ hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hip
 hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* z, const void* lam, int set_rho,
                                 int rho_ind, hipStream_t s);
 hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
+hipError_t rqp_launch_ruiz(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_scale_vecs(const rqp_handle* h, void* g, void* l, void* u, hipStream_t s);
+hipError_t rqp_launch_scale_state(const rqp_handle* h, double* x, double* z, double* lam, hipStream_t s);
+hipError_t rqp_launch_unscale_out(const rqp_handle* h, void* x, void* z, void* lam, double* obj, hipStream_t s);
 hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
 

@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
         inst[16 + 2] = (float)a.thr_d;
         inst[16 + 3] = (float)a.rho_min;
         inst[16 + 4] = (float)a.rho_max;
+        inst[16 + 5] = (float)a.eps_rel;
     }
     // row state (wave w owns rows [16 MBW w, 16 MBW (w+1)); lane: slot i16, rows 16 T + 4 kq + r); the low word of A x lives in ZL
     float zh[MBW][4], zz[MBW][4], lm[MBW][4];
@@ -670,7 +671,10 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         double* tr = a.info.trace + ((size_t)id * a.info.trace_cap + (chk_no - 1)) * 4;
                         tr[0] = (double)q0; tr[1] = (double)q3; tr[2] = (double)est; tr[3] = (double)ri_before;
                     }
-                    const bool conv = !final_chk && (q0 < thr_p && q3 < thr_d);           // :233
+                    const float er = inst[16 + 5];                                        // eps_rel (0: the reference's absolute test)
+                    const float tp = er > 0.f ? thr_p + er * nanmaxf(q1, q2) : thr_p;
+                    const float td = er > 0.f ? thr_d + er * nanmaxf(nanmaxf(q4, q5), q6) : thr_d;
+                    const bool conv = !final_chk && (q0 < tp && q3 < td);                 // :233
                     const bool last = final_chk || kc >= kmax;                             // :243 max-iter fallthrough
                     if (conv || last) {
                         float est_out = est;
@@ -684,7 +688,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         inst_i[5 * 16 + j] = 1;
                         const size_t bj = (size_t)id;
                         if (a.info.iter) a.info.iter[bj] = conv ? kc : a.max_iter;
-                        if (a.info.status) a.info.status[bj] = conv ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+                        if (a.info.status) a.info.status[bj] = conv ? RQP_STATUS_SOLVED : ((q0 != q0 || q3 != q3) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
                         if (a.info.rho_ind) a.info.rho_ind[bj] = ri;
                         if (a.info.pri_res) a.info.pri_res[bj] = (double)q0;
                         if (a.info.dua_res) a.info.dua_res[bj] = (double)q3;

@@ -450,6 +450,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     row_pass(true, false, kmax > 0);
 
     // ---- compute_residuals (reluqpth.py:307-318) on the current state (hx = H x valid)
+    float scl_p = 0.f, scl_d = 0.f;                                    // residual scales of the last check (eps_rel)
     auto residuals = [&](float rho_carry, float& o_pri, float& o_dua) -> float {
         float v[7];
 #pragma unroll
@@ -502,8 +503,10 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         __syncthreads();
         o_pri = v[0];
         o_dua = v[3];
-        const float num = v[0] / tmax2(v[1], v[2]);
-        const float den = v[3] / tmax2(tmax2(v[4], v[5]), v[6]);
+        scl_p = tmax2(v[1], v[2]);
+        scl_d = tmax2(tmax2(v[4], v[5]), v[6]);
+        const float num = v[0] / scl_p;
+        const float den = v[3] / scl_d;
         float est = rho_carry * sqrtf(num / den);
         if (est < (float)a.rho_min) est = (float)a.rho_min;             // torch.clamp: NaN stays NaN
         if (est > (float)a.rho_max) est = (float)a.rho_max;
@@ -574,7 +577,12 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
                 tr[0] = (double)pri; tr[1] = (double)dua; tr[2] = (double)rho_est; tr[3] = (double)ri_before;
             }
-            if (pri < (float)a.thr_p && dua < (float)a.thr_d) {        // :233
+            float tp = (float)a.thr_p, td = (float)a.thr_d;            // :233 (+ relative term when eps_rel > 0, 8(f)-3)
+            if (a.eps_rel > 0) {
+                tp += (float)a.eps_rel * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scl_p)));
+                td += (float)a.eps_rel * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scl_d)));
+            }
+            if (pri < tp && dua < td) {
                 converged = true;
                 break;
             }
@@ -627,7 +635,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     if (tid == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
-        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
         if (a.info.dua_res) a.info.dua_res[b] = (double)dua;

@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     const int kmax = a.max_iter;
 
     // compute_residuals (:307-318) on the current state; leaves H x of the column in hx
+    T scl_p = (T)0, scl_d = (T)0;                                       // residual scales of the last check (eps_rel)
     auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
         T w0 = (T)0, w1 = (T)0, w2 = (T)0;
 #pragma unroll
@@ -215,8 +216,10 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
         if constexpr (NWV > 1) __syncthreads();                         // redL is reused by the next check
         o_pri = v0;
         o_dua = v3;
-        const T num = v0 / wtmax(v1, v2);                               // :315
-        const T den = v3 / wtmax(wtmax(v4, v5), v6);                    // :316
+        scl_p = wtmax(v1, v2);
+        scl_d = wtmax(wtmax(v4, v5), v6);
+        const T num = v0 / scl_p;                                       // :315
+        const T den = v3 / scl_d;                                       // :316
         T est = rho_carry * (T)sqrt(num / den);                         // :317
         if (est < (T)a.rho_min) est = (T)a.rho_min;                     // torch.clamp: NaN stays NaN
         if (est > (T)a.rho_max) est = (T)a.rho_max;
@@ -271,7 +274,9 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
                     inv[q] = 1.0 / (double)rv[q];
                 }
             }
-            if (pri < (T)a.thr_p && dua < (T)a.thr_d) {                 // :233
+            const T tp = a.eps_rel > 0 ? (T)a.thr_p + (T)a.eps_rel * scl_p : (T)a.thr_p;      // :233 (+ relative term, 8(f)-3)
+            const T td = a.eps_rel > 0 ? (T)a.thr_d + (T)a.eps_rel * scl_d : (T)a.thr_d;
+            if (pri < tp && dua < td) {
                 converged = true;
                 break;
             }
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     if (threadIdx.x == 0) {
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
-        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : RQP_STATUS_MAX_ITER;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
         if (a.info.dua_res) a.info.dua_res[b] = (double)dua;

@@ -70,11 +70,15 @@ def test_random_qps_harness_vs_oracle():
 def test_update_matrices_vs_oracle(prec, tol, n, n_eq, n_ineq, B):
     """update(Hx=, Ax=): pack -> gram -> factor -> kernel images re-run on the device, state kept.  The oracle defines the
     semantics (the reference asserts): new matrices, K ladder rebuilt with the equality pattern of setup, carried state."""
-    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=40, feasible=True)
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=40, feasible=True)
     rs = np.random.RandomState(1)
     M = 0.1 * rs.randn(B, n, n)
     H2 = H + np.einsum("bij,bkj->bik", M, M)                        # still SPD
-    A2 = A + 0.05 * rs.randn(*A.shape)
+    # perturb A orthogonally to the planted point: A2 xs = A xs, so the planted point stays feasible with the same active
+    # set (a free perturbation of the degenerate planted vertex -- more active rows than free dimensions -- is infeasible)
+    dA = 0.05 * rs.randn(*A.shape)
+    dA -= np.einsum("bmn,bn->bm", dA, xs)[:, :, None] * xs[:, None, :] / np.einsum("bn,bn->b", xs, xs)[:, None, None]
+    A2 = A + dA
     m = _solver(H, g, A, l, u, precision=prec)
 
     def snap():                       # solve() returns the solver's ONE Results object (as the reference): copy what is compared

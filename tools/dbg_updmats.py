@@ -5,24 +5,22 @@ import numpy as np, torch
 from oracle import reluqp_oracle as O
 from reluqp import utils
 import reluqp.reluqpth as reluqpth
-B, n, n_eq, n_ineq = 6, 10, 3, 12
+B, n, n_eq, n_ineq = 4, 100, 25, 275
 H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=40, feasible=True)
 rs = np.random.RandomState(1)
 M = 0.1 * rs.randn(B, n, n)
 H2 = H + np.einsum("bij,bkj->bik", M, M)
-for kern in ("auto", "generic"):
-    m = reluqpth.ReLU_QP(); m.collect_trace = True
-    m.setup(H, g, A, l, u, device=torch.device("cuda:0"), precision=torch.float64, kernel=kern)
-    r0 = m.solve()
-    print(kern, "r0 it", r0.info.iter.tolist(), "ri", r0.info.rho_ind.tolist())
-    m.update(Hx=H2)
-    r1 = m.solve()
-    print(kern, "r1 it", r1.info.iter.tolist(), "ri", r1.info.rho_ind.tolist())
-    print(" trace b=1", m.last_trace[1][:6].cpu().numpy())
-    K = m.layers.K(7, 1).cpu().numpy()
-    Kref = np.linalg.inv(H2[1] + 1e-6 * np.eye(n) + A[1].T @ (O.rho_vector(0.1, l[1], u[1], 1e-6)[:, None] * A[1]))
-    print(" K err", np.abs(K - Kref).max(), np.abs(Kref).max())
-for b in range(B):
-    qp = O.OracleQP(form="factored"); qp.setup(H[b], g[b], A[b], l[b], u[b]); a0 = qp.solve(); i0, r0_ = a0.info.iter, qp.rho_ind
-    qp.update(Hx=H2[b]); a1 = qp.solve()
-    print("oracle b", b, "a0", i0, r0_, "a1", a1.info.iter, qp.rho_ind, qp.trace[:3] if b == 1 else "")
+A2 = A + 0.05 * rs.randn(*A.shape)
+def tight(Hb, Ab, b):
+    qp = O.OracleQP(form="factored"); qp.setup(Hb, g[b], Ab, l[b], u[b], eps_abs=1e-8, max_iter=20000); return qp.solve().x
+xs = {"HA": tight(H[0], A[0], 0), "H2A": tight(H2[0], A[0], 0), "H2A2": tight(H2[0], A2[0], 0), "HA2": tight(H[0], A2[0], 0)}
+for kern in ("resident", "generic"):
+    m = reluqpth.ReLU_QP()
+    m.setup(H, g, A, l, u, device=torch.device("cuda:0"), precision=torch.float32, kernel=kern, eps_abs=1e-5, max_iter=20000)
+    def show(tag):
+        r = m.solve(); x = r.x[0].cpu().double().numpy()
+        print(kern, tag, "it", r.info.iter.tolist(), {k: float(np.abs(x - v).max()) for k, v in xs.items()})
+    show("setup      ")
+    m.update(Hx=H2); show("Hx=H2      ")
+    m.update(Ax=A2); show("Ax=A2      ")
+    m.update(Hx=H, Ax=A); show("Hx=H,Ax=A  ")
