@@ -100,6 +100,30 @@ def rho_vector(rho_scalar, l, u, eq_tol):
     return rho
 
 
+# ------------------------------------------------------- build extension: scaling
+def ruiz_scale(H, A, passes):
+    """Modified Ruiz equilibration of the KKT matrix [[H, A'], [A, 0]] (OSQP's scaling; the reference only carries a
+    `scaling` TODO, reluqpth.py:105,335).  Statement of csrc/rqp_scale.hip:k_ruiz, same order of operations:
+    returns (D[n], E[m], c, Hbar = c D H D, Abar = E A D)."""
+    n, m = H.shape[0], A.shape[0]
+    Hs, As = H.astype(np.float64).copy(), A.astype(np.float64).copy()
+    D, E = np.ones(n), np.ones(m)
+
+    def lim(nrm):
+        nrm = np.where(nrm < 1e-4, 1.0, nrm)
+        return 1.0 / np.sqrt(np.minimum(nrm, 1e4))
+    for _ in range(passes):
+        dl = lim(np.maximum(np.abs(Hs).max(axis=0), np.abs(As).max(axis=0) if m else 0.0))
+        ep = lim(np.abs(As).max(axis=1))
+        Hs = (Hs * dl[:, None]) * dl[None, :]
+        As = (As * ep[:, None]) * dl[None, :]
+        D, E = D * dl, E * ep
+    cv = np.abs(Hs).max(axis=0).sum() / n if passes > 0 else 1.0
+    cv = 1.0 if cv < 1e-4 else min(cv, 1e4)
+    c = 1.0 / cv
+    return D, E, c, Hs * c, As
+
+
 # --------------------------------------------------------------------------- a4
 def kkt_inverse(H, A, rho_vec, sigma):
     """K = inverse(H + sigma I + A' diag(rho) A), reluqpth.py:56."""
@@ -238,6 +262,28 @@ def compute_residuals(H, A, g, x, z, lam, rho, rho_min, rho_max):
     return pri, dua, T(est)
 
 
+def infeasibility_certificate(H, A, g, l, u, x, z, dx, rho_vec, eps_prim_inf, eps_dual_inf):
+    """Build extension (the reference has no infeasibility test): OSQP's certificates on
+    dy = rho (A x - z) -- the dual increment the next iteration applies, projected on the polar of the recession cone of
+    [l, u] -- and on dx, the last x step.  Returns STATUS_PRIMAL_INFEASIBLE / STATUS_DUAL_INFEASIBLE / None.
+    Statement of csrc/rqp_admm.hip:certificates."""
+    dy = rho_vec * (A @ x - z)
+    uinf, linf = np.isposinf(u), np.isneginf(l)
+    dy = np.where(uinf & linf, 0.0, np.where(uinf, np.minimum(dy, 0.0), np.where(linf, np.maximum(dy, 0.0), dy)))
+    ndy = np.abs(dy).max() if dy.size else 0.0
+    with np.errstate(invalid="ignore"):
+        lhs = np.sum(np.where(dy > 0, u * dy, 0.0)) + np.sum(np.where(dy < 0, l * dy, 0.0))
+    if ndy > 0 and lhs < -eps_prim_inf * ndy and np.abs(A.T @ dy).max() < eps_prim_inf * ndy:
+        return STATUS_PRIMAL_INFEASIBLE
+    ndx = np.abs(dx).max()
+    Adx = A @ dx
+    tol = eps_dual_inf * ndx
+    bad = np.any((~uinf & (Adx > tol)) | (~linf & (Adx < -tol)))
+    if ndx > 0 and g @ dx < -eps_dual_inf * ndx and np.abs(H @ dx).max() < eps_dual_inf * ndx and not bad:
+        return STATUS_DUAL_INFEASIBLE
+    return None
+
+
 def compute_J(H, g, x):
     """Objective, reluqpth.py:320-322."""
     return 0.5 * np.dot(x, H @ x) + np.dot(g, x)
@@ -294,7 +340,17 @@ class OracleQP:
         self.l = np.ascontiguousarray(l, dtype=dt)
         self.u = np.ascontiguousarray(u, dtype=dt)
         self.nx, self.nc = self.H.shape[0], self.A.shape[0]
-        self._lu_setup = (self.l.copy(), self.u.copy())    # the equality pattern (rho x 1e3 rows) is fixed at setup
+        self._lu_setup = (self.l.copy(), self.u.copy())    # the equality pattern (rho x 1e3 rows) is fixed at setup (raw l, u)
+        self._sc = None
+        passes = 10 if st.scaling is True else int(st.scaling or 0)
+        if passes > 0:                                     # build extension (8(f)-3): solve the equilibrated problem
+            assert not self.quirks, "the reference has no scaling"
+            D, E, c, Hs, As = ruiz_scale(self.H, self.A, passes)
+            self._sc = (D, E, c)
+            self.H, self.A = Hs.astype(dt), As.astype(dt)
+            self.g = (self.g.astype(np.float64) * (c * D)).astype(dt)
+            self.l = (self.l.astype(np.float64) * E).astype(dt)
+            self.u = (self.u.astype(np.float64) * E).astype(dt)
         self.rhos = setup_rhos(st.rho, st.rho_min, st.rho_max, st.adaptive_rho_tolerance,
                                st.adaptive_rho).astype(dt)
         self._build_matrices()
@@ -333,19 +389,27 @@ class OracleQP:
         built at setup (W_ks untouched, :171-174)."""
         t0 = time.perf_counter()
         dt = self.settings.dtype
+        sc = getattr(self, "_sc", None)
         if g is not None:
             self.g = np.ascontiguousarray(g, dtype=dt)
+            if sc is not None:
+                self.g = (self.g.astype(np.float64) * (sc[2] * sc[0])).astype(dt)
             if self.form == "W":
                 self.b_ks = [B @ self.g for B in self.B_ks]
         if l is not None:
             self.l = np.ascontiguousarray(l, dtype=dt)
+            if sc is not None:
+                self.l = (self.l.astype(np.float64) * sc[1]).astype(dt)
         if u is not None:
             self.u = np.ascontiguousarray(u, dtype=dt)
+            if sc is not None:
+                self.u = (self.u.astype(np.float64) * sc[1]).astype(dt)
         if Hx is not None or Ax is not None:
             # The reference asserts here ("updating Hx and Ax is not supported yet", reluqpth.py:176-177).  The build
             # defines it (SURVEY.md 8(f)-4) as: new dense H / A, the matrices of setup_matrices (:40-78) rebuilt with the
             # equality pattern of setup, state and rho index carried -- this restatement is that definition.
             assert not self.quirks, "updating Hx and Ax is not supported yet"
+            assert sc is None, "matrix updates with scaling: set up again"
             if Hx is not None:
                 self.H = np.ascontiguousarray(Hx, dtype=dt)
             if Ax is not None:
@@ -372,6 +436,11 @@ class OracleQP:
         iterate); quirks=False: written into the state."""
         n, m = self.nx, self.nc
         dt = self.settings.dtype
+        sc = getattr(self, "_sc", None)
+        if sc is not None:                                 # caller space -> scaled space
+            x = None if x is None else np.asarray(x, np.float64) / sc[0]
+            z = None if z is None else np.asarray(z, np.float64) * sc[1]
+            lam = None if lam is None else np.asarray(lam, np.float64) * (sc[2] / sc[1])
         if x is not None:
             self.x = np.asarray(x, dt).copy()
             if not self.quirks:
@@ -432,6 +501,7 @@ class OracleQP:
         tol = st.adaptive_rho_tolerance
         self.trace = []
         for k in range(1, st.max_iter + 1):
+            x_prev = self.output[:n].copy()
             self._iterate()                                # :215
             do_check = (k % st.check_interval == 0)
             if self.quirks:
@@ -455,6 +525,13 @@ class OracleQP:
                 if pri < tp and dua < td:                  # :233
                     self._update_results(k, STATUS_SOLVED, pri, dua, rho, t0)
                     return self.results
+                if st.check_infeasibility and not self.quirks:
+                    rv = rho_vector(self.rhos[self.rho_ind], *self._lu_setup, st.eq_tol)
+                    code = infeasibility_certificate(self.H, self.A, self.g, self.l, self.u, self.x, self.z,
+                                                     self.x - x_prev, rv, st.eps_prim_inf, st.eps_dual_inf)
+                    if code is not None:
+                        self._update_results(k, code, pri, dua, rho, t0)
+                        return self.results
         if not self.quirks:                                # Q11 fix: re-slice
             s = self.output
             self.x, self.z, self.lam = s[:n], s[n:n + m], s[n + m:]
@@ -473,10 +550,17 @@ class OracleQP:
         self.results.x = self.x.copy()
         self.results.z = self.z.copy()
         self.results.lam = self.lam.copy()
-        self.results.y = self.lam.copy()                   # Q7 extension: dual of the state
+        self.info.obj_val = compute_J(self.H, self.g, self.x)
+        sc = getattr(self, "_sc", None)
+        if sc is not None:                                 # scaled space -> caller space (residuals stay scaled)
+            D, E, c = sc
+            self.results.x = self.results.x * D
+            self.results.z = self.results.z / E
+            self.results.lam = self.results.lam * (E / c)
+            self.info.obj_val = self.info.obj_val / c
+        self.results.y = self.results.lam.copy()           # Q7 extension: dual of the state
         self.info.iter = it
         self.info.status = status
-        self.info.obj_val = compute_J(self.H, self.g, self.x)
         self.info.pri_res = pri
         self.info.dua_res = dua
         self.info.rho_estimate = rho

@@ -109,6 +109,9 @@ SolveArgs make_solve_args(const rqp_handle* h) {
     a.thr_p = h->st.eps_abs * std::sqrt((double)h->m);   // reluqpth.py:233
     a.thr_d = h->st.eps_abs * std::sqrt((double)h->n);
     a.eps_rel = h->st.eps_rel;
+    a.check_infeas = h->st.check_infeasibility;
+    a.eps_pinf = h->st.eps_prim_inf;
+    a.eps_dinf = h->st.eps_dual_inf;
     a.Ht = h->Ht; a.A = h->A; a.At = h->At; a.K = h->K;
     const bool sh = h->dims.shared_mats != 0;
     a.sH = sh ? 0 : (size_t)h->n * h->ldn;
@@ -455,7 +458,19 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         a.order = h->order_valid ? h->order_d : nullptr;
         a.last_iter = h->last_iter_d;
     }
+    // Infeasibility certificates: the streaming kernel tests them at every check; the register-resident / MFMA kernels
+    // keep their loops untouched and a mode-3 pass of the streaming kernel examines the instances that ran out of iterations.
+    const bool post_cert = h->st.check_infeasibility && a.info.status && (h->use_mfma || h->use_wave || h->resident);
+    if (post_cert) a.keep_state = 1;
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
+    if (post_cert) {
+        SolveArgs c = a;
+        c.mode = 3;
+        c.order = nullptr;
+        c.last_iter = nullptr;
+        c.keep_state = 0;
+        HIP_TRY(h, rqp_launch_solve_generic(h, c, (hipStream_t)stream));
+    }
     if (h->order_d) {                               // rank the instances by what they just needed: next launch goes longest-first
         HIP_TRY(h, rqp_launch_order_lpt(h, (hipStream_t)stream));
         h->order_valid = true;

@@ -103,6 +103,17 @@ __device__ void block_max(T (&v)[NV], T* red /* LDS [NV * 4] */) {
     __syncthreads();
 }
 
+// sum over the workgroup (fixed order: wave shuffles, then the 4 wave sums), broadcast to all; scratch >= 4 doubles of LDS
+__device__ double block_sum(double v, double* scratch) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, RQP_WAVE);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    __syncthreads();
+    return r;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -134,6 +145,20 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     const T* At = (const T*)a.At + (size_t)b * a.sAt;
     const T* Kb = (const T*)a.K + (size_t)b * a.sK;
 
+    if (a.mode == 3) {                       // certificate pass behind another solve kernel (rqp_solve): only the instances that
+        const bool todo = a.info.status[b] == RQP_STATUS_MAX_ITER;      // spent their iterations are examined; the state the
+        if (!todo) {                                                    // solve kernel was asked to keep is cleared here
+            if (!a.warm_starting) {
+                for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = 0.0;
+                for (int i = tid; i < m; i += RQP_NT) {
+                    a.z[(size_t)b * m + i] = 0.0;
+                    a.lam[(size_t)b * m + i] = 0.0;
+                }
+                if (tid == 0) a.rho_ind[b] = a.rho_ind0;
+            }
+            return;
+        }
+    }
     for (int i = tid; i < n; i += RQP_NT) {
         xs[i] = a.x[(size_t)b * n + i];
         gT[i] = ((const T*)a.g)[(size_t)b * n + i];
@@ -158,7 +183,57 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     int iters = 0;
     T pri = T(0), dua = T(0);
     const T tolT = (T)a.tol;
-    const int kmax = (a.mode == 2) ? 0 : a.max_iter;
+    const int kmax = (a.mode == 2) ? 0 : ((a.mode == 3) ? 1 : a.max_iter);
+    int cert = 0;                             // RQP_STATUS_PRIMAL_INFEASIBLE / RQP_STATUS_DUAL_INFEASIBLE once a certificate holds
+
+    // ---- infeasibility certificates (the reference has none: reluqpth.py:233 only tests residuals).
+    // OSQP's tests on the directions of the last iteration: dy = rho (A x - z), the dual increment the next iteration will
+    // apply (projected on the polar of the recession cone of [l, u]), and dx, the x step just taken (dv), with A dx in vm.
+    //   primal infeasible:  u' max(dy,0) + l' min(dy,0) < -eps |dy|  and  |A' dy| < eps |dy|
+    //   dual infeasible:    g' dx < -eps |dx|,  |H dx| < eps |dx|,  (A dx)_i <= eps |dx| where u_i is finite, >= -eps |dx| where l_i is
+    // Uses vin, vn, part as scratch (hx, the state and dv / vm are left intact).
+    auto certificates = [&]() -> int {
+        const T inf = (T)INFINITY;
+        T ndy = T(0);
+        double lhs = 0.0;
+        for (int i = tid; i < m; i += RQP_NT) {
+            T dy = (T)((double)rvT[i] * (zts[i] - zs[i]));
+            const bool uinf = uT[i] == inf, linf = lT[i] == -inf;
+            if (uinf && linf) dy = T(0);
+            else if (uinf) dy = dy < T(0) ? dy : T(0);
+            else if (linf) dy = dy > T(0) ? dy : T(0);
+            vin[i] = dy;
+            ndy = tmax(ndy, (T)fabs(dy));
+            if (dy > T(0)) lhs += (double)uT[i] * (double)dy;
+            if (dy < T(0)) lhs += (double)lT[i] * (double)dy;
+        }
+        __syncthreads();
+        colmv<T>(A, ldn, m, n, vin, vn, part);                     // A' dy
+        T nat = T(0), ndx = T(0);
+        double gdx = 0.0;
+        for (int i = tid; i < n; i += RQP_NT) {
+            nat = tmax(nat, (T)fabs(vn[i]));
+            ndx = tmax(ndx, (T)fabs(dv[i]));
+            gdx += (double)gT[i] * (double)dv[i];
+        }
+        __syncthreads();
+        colmv<T>(Ht, ldn, n, n, dv, vn, part);                     // H dx
+        T nhdx = T(0);
+        for (int i = tid; i < n; i += RQP_NT) nhdx = tmax(nhdx, (T)fabs(vn[i]));
+        T mx[4] = {ndy, nat, ndx, nhdx};
+        block_max<T, 4>(mx, red);
+        lhs = block_sum(lhs, (double*)part);
+        gdx = block_sum(gdx, (double*)part);
+        const T ep = (T)a.eps_pinf, ed = (T)a.eps_dinf;
+        if (mx[0] > T(0) && lhs < -(double)(ep * mx[0]) && mx[1] < ep * mx[0]) return RQP_STATUS_PRIMAL_INFEASIBLE;
+        double bad = 0.0;
+        const T tol = ed * mx[2];
+        for (int i = tid; i < m; i += RQP_NT)
+            if ((uT[i] < inf && vm[i] > tol) || (lT[i] > -inf && vm[i] < -tol)) bad = 1.0;
+        bad = block_sum(bad, (double*)part);
+        if (mx[2] > T(0) && gdx < -(double)(ed * mx[2]) && mx[3] < ed * mx[2] && bad == 0.0) return RQP_STATUS_DUAL_INFEASIBLE;
+        return 0;
+    };
 
     // ---- residuals of the current state (compute_residuals, reluqpth.py:307-318) ----------
     // leaves H x in hx (hx_valid), returns pri/dua and the new carried rho estimate
@@ -260,7 +335,24 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
                 converged = true;
                 break;
             }
+            if (a.check_infeas) {
+                cert = certificates();
+                if (cert) break;
+            }
         }
+    }
+    if (a.mode == 3) {                                             // one iteration taken from the persisted state: its directions
+        cert = certificates();
+        if (tid == 0 && cert) a.info.status[b] = cert;
+        if (!a.warm_starting) {                                    // the solve kernel kept the state for this pass only
+            for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = 0.0;
+            for (int i = tid; i < m; i += RQP_NT) {
+                a.z[(size_t)b * m + i] = 0.0;
+                a.lam[(size_t)b * m + i] = 0.0;
+            }
+            if (tid == 0) a.rho_ind[b] = a.rho_ind0;
+        }
+        return;
     }
 
     if (a.mode == 1) {                                             // iterate-only: keep the state
@@ -271,7 +363,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
         }
         return;
     }
-    if (!converged) rho_est = residuals(rho_est, pri, dua);        // :243 (Q11 fixed: fresh state)
+    if (!converged && !cert) rho_est = residuals(rho_est, pri, dua);   // :243 (Q11 fixed: fresh state)
 
     // objective 1/2 x'Hx + g'x (compute_J :320-322): hx holds H x of the final state
     double jp = 0.0;
@@ -297,16 +389,18 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     if (a.out_z) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_z)[(size_t)b * m + i] = (T)zs[i];
     if (a.out_lam) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_lam)[(size_t)b * m + i] = (T)ls[i];
     if (tid == 0) {
-        if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
-        if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
-        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
+        if (a.info.iter) a.info.iter[b] = (converged || cert) ? iters : a.max_iter;
+        if (a.last_iter) a.last_iter[b] = (converged || cert) ? iters : a.max_iter;
+        if (a.info.status)
+            a.info.status[b] = converged ? RQP_STATUS_SOLVED
+                                         : (cert ? cert : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER));
         if (a.info.rho_ind) a.info.rho_ind[b] = ri;
         if (a.info.pri_res) a.info.pri_res[b] = (double)pri;
         if (a.info.dua_res) a.info.dua_res[b] = (double)dua;
         if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
         if (a.info.obj_val) a.info.obj_val[b] = obj;
     }
-    if (a.warm_starting) {                                         // state + rho index persist (:304)
+    if (a.warm_starting || a.keep_state) {                         // state + rho index persist (:304)
         for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = xs[i];
         for (int i = tid; i < m; i += RQP_NT) {
             a.z[(size_t)b * m + i] = zs[i];

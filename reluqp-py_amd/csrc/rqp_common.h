@@ -71,8 +71,12 @@ struct rqp_handle {
 struct SolveArgs {
     int n, m, ldn, ldm, nrho, B;
     int max_iter, check_interval, warm_starting, rho_ind0;
-    int mode;                 // 0 solve, 1 iterate-only (k = max_iter), 2 residuals-only
+    int mode;                 // 0 solve, 1 iterate-only (k = max_iter), 2 residuals-only, 3 certificates of the persisted state
     double sigma, tol, rho_min, rho_max, thr_p, thr_d, rho_in;
+    double eps_pinf, eps_dinf;   // infeasibility certificates (check_infeas)
+    int check_infeas;         // 1: test the OSQP certificates (generic kernel: at every check; others: rqp_solve runs the
+                              //    generic kernel in mode 3 afterwards on the instances that spent their iterations)
+    int keep_state;           // 1: persist the state even when warm_starting = 0 (a mode-3 pass follows and clears it)
     double eps_rel;           // 0: absolute test only (reluqpth.py:233); > 0: thresholds grow by eps_rel * the residual's scale
     const void *Ht, *A, *At, *K;
     size_t sH, sA, sAt, sK;   // per-instance strides in elements (0 when shared)

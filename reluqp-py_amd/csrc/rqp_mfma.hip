@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         if (a.info.dua_res) a.info.dua_res[bj] = (double)q3;
                         if (a.info.rho_estimate) a.info.rho_estimate[bj] = (double)est_out;
                         if (a.info.obj_val) a.info.obj_val[bj] = (double)obj;
-                        a.rho_ind[bj] = a.warm_starting ? ri : a.rho_ind0;
+                        a.rho_ind[bj] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
                         if (refill) {                    // this slot takes the next unsolved instance
                             const int nxt = (int)gridDim.x * 16 + atomicAdd(queue, 1);
                             if (nxt < a.B) {
@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     if (row < n_o) {
                         const size_t o = (size_t)oid * n_o + row;
                         if (a.out_x) ((float*)a.out_x)[o] = xr[e];
-                        a.x[o] = a.warm_starting ? (double)xr[e] : 0.0;
+                        a.x[o] = (a.warm_starting || a.keep_state) ? (double)xr[e] : 0.0;
                     }
                 }
                 if ((m_o & 3) == 0) {                        // 16 B / 32 B stores: the lane's 4 rows of a tile are contiguous
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                             const f32x4 y4 = {lm[tl][0], lm[tl][1], lm[tl][2], lm[tl][3]};
                             if (a.out_z) *(f32x4*)((float*)a.out_z + o) = z4;
                             if (a.out_lam) *(f32x4*)((float*)a.out_lam + o) = y4;
-                            const bool ws = a.warm_starting != 0;
+                            const bool ws = (a.warm_starting || a.keep_state) != 0;
                             *(f64x2*)(a.z + o) = (f64x2){ws ? (double)z4[0] : 0.0, ws ? (double)z4[1] : 0.0};
                             *(f64x2*)(a.z + o + 2) = (f64x2){ws ? (double)z4[2] : 0.0, ws ? (double)z4[3] : 0.0};
                             *(f64x2*)(a.lam + o) = (f64x2){ws ? (double)y4[0] : 0.0, ws ? (double)y4[1] : 0.0};
@@ -765,8 +765,8 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                                 const size_t o = (size_t)oid * m_o + row;
                                 if (a.out_z) ((float*)a.out_z)[o] = zz[tl][r];
                                 if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
-                                a.z[o] = a.warm_starting ? (double)zz[tl][r] : 0.0;
-                                a.lam[o] = a.warm_starting ? (double)lm[tl][r] : 0.0;
+                                a.z[o] = (a.warm_starting || a.keep_state) ? (double)zz[tl][r] : 0.0;
+                                a.lam[o] = (a.warm_starting || a.keep_state) ? (double)lm[tl][r] : 0.0;
                             }
                         }
                 }

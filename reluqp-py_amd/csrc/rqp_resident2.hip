@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
         if (a.info.obj_val) a.info.obj_val[b] = obj;
     }
-    if (a.warm_starting) {                                             // state + rho index persist (:304)
+    if ((a.warm_starting || a.keep_state)) {                                             // state + rho index persist (:304)
         for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = x64[SW * (i / CW) + i % CW];
         for (int i = tid; i < m; i += NT) {
             a.z[(size_t)b * m + i] = z64[i];

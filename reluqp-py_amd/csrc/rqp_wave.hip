@@ -306,17 +306,17 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
         if (a.info.dua_res) a.info.dua_res[b] = (double)dua;
         if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
         if (a.info.obj_val) a.info.obj_val[b] = jp;
-        a.rho_ind[b] = a.warm_starting ? ri : a.rho_ind0;
+        a.rho_ind[b] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
     }
-    if (h == 0 && cok) a.x[(size_t)b * n + c] = a.warm_starting ? x : 0.0;           // state persists (:304) or is cleared (:324-333)
+    if (h == 0 && cok) a.x[(size_t)b * n + c] = (a.warm_starting || a.keep_state) ? x : 0.0;           // state persists (:304) or is cleared (:324-333)
 #pragma unroll
     for (int q = 0; q < RL; ++q) {
         const int r = r0 + 64 * q;
         if (r < m) {
             if (a.out_z) ((T*)a.out_z)[(size_t)b * m + r] = (T)z[q];
             if (a.out_lam) ((T*)a.out_lam)[(size_t)b * m + r] = (T)lam[q];
-            a.z[(size_t)b * m + r] = a.warm_starting ? z[q] : 0.0;
-            a.lam[(size_t)b * m + r] = a.warm_starting ? lam[q] : 0.0;
+            a.z[(size_t)b * m + r] = (a.warm_starting || a.keep_state) ? z[q] : 0.0;
+            a.lam[(size_t)b * m + r] = (a.warm_starting || a.keep_state) ? lam[q] : 0.0;
         }
     }
 }

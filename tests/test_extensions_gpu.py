@@ -293,3 +293,194 @@ def test_fp16_tile_same_exits_as_float32(shape):
     assert ei.value.code == _cabi.RQP_ERR_UNSUPPORTED
     with pytest.raises(ValueError):
         reluqpth.ReLU_QP().setup(H, g, A, l, u, device=DEV, precision=torch.float64, iterate_dtype=torch.float16)
+
+
+# ------------------------------------------------------------------------------------------ f3
+def _badly_scaled(B, n, n_eq, n_ineq, seed0):
+    """rand_qp with the variables rescaled by 1e-2 .. 1e2 and the rows by 1e-1 .. 1e1: same optimum x / s."""
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=seed0, feasible=True)
+    s = np.logspace(-2, 2, n)
+    r = np.logspace(-1, 1, n_eq + n_ineq)
+    Hb = H * s[None, :, None] * s[None, None, :]
+    Ab = A * s[None, None, :] * r[None, :, None]
+    return Hb, g * s[None], Ab, l * r[None], u * r[None], xs / s[None]
+
+
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kernel,n,n_eq,n_ineq", [("generic", 20, 5, 30), ("wave", 20, 5, 30), ("resident", 60, 15, 100)])
+def test_eps_rel_matches_oracle(prec, kernel, n, n_eq, n_ineq):
+    """eps_rel > 0 (C-ABI rqp_settings.eps_rel): OSQP-style thresholds eps_abs sqrt(dim) + eps_rel * scale.  Same exits as
+    the oracle with the same extension; eps_rel = 0 is bit-for-bit the reference's test (every other test of this suite)."""
+    if kernel == "resident" and prec == torch.float64:
+        pytest.skip("resident tiles are float32")
+    B = 6
+    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=70, feasible=True)
+    kw = dict(eps_abs=1e-7, eps_rel=1e-3)
+    m = _solver(H, g, A, l, u, precision=prec, kernel=kernel, **kw)
+    r = m.solve()
+    ref = O.solve_batch(H, g, A, l, u, form="factored", **kw)
+    ref0 = O.solve_batch(H, g, A, l, u, form="factored", eps_abs=1e-7)
+    assert np.all(ref["iter"] < ref0["iter"])                         # the relative term ends these solves earlier
+    it = r.info.iter.cpu().numpy()
+    assert list(r.info.status) == ref["status"]
+    if prec == torch.float64:
+        assert np.array_equal(it, ref["iter"])
+    else:
+        assert np.mean(it == ref["iter"]) >= 0.8 and np.all(np.abs(it - ref["iter"]) <= 50)
+    same = it == ref["iter"]
+    np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0,
+                               atol=(1e-7 if prec == torch.float64 else 5e-5) * max(1.0, np.abs(ref["x"]).max()))
+    m.update_settings(eps_rel=0.0, eps_abs=1e-3)                      # changeable after setup
+    assert all(s == "solved" for s in m.solve().info.status)
+
+
+def test_eps_rel_mfma_shared_batch():
+    from reluqp import mpc
+    Ad, Bd = mpc.random_plant(6, 2, seed=7)
+    ctl = mpc.LinearMPC(Ad, Bd, np.eye(6), 0.1 * np.eye(2), 10, 0.4, 8.0, form="condensed")
+    x0 = 1.5 * np.random.RandomState(7).randn(40, 6)
+    g, l, u = ctl.qp_vectors(x0)
+    kw = dict(eps_abs=1e-6, eps_rel=1e-3)
+    ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", **kw)
+    m = _solver(ctl.H, g, ctl.A, l, u, precision=torch.float32, kernel="mfma", **kw)
+    r = m.solve()
+    it = r.info.iter.cpu().numpy()
+    assert list(r.info.status) == ref["status"]
+    assert np.mean(it == ref["iter"]) >= 0.8
+
+
+@pytest.mark.parametrize("prec,tol", [(torch.float64, 1e-6), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("kernel,n,n_eq,n_ineq", [("generic", 20, 5, 30), ("wave", 20, 5, 30), ("resident", 60, 15, 100)])
+def test_ruiz_scaling_vs_oracle(prec, tol, kernel, n, n_eq, n_ineq):
+    """settings.scaling = k Ruiz passes at setup (the reference's `scaling` is an unused TODO, reluqpth.py:105): the
+    equilibrated problem is solved, every ABI boundary converts.  Against the oracle with the same scaling: same exits,
+    same un-scaled x, z, y, objective; warm_start / get_state / update round-trip in the caller's space."""
+    if kernel == "resident" and prec == torch.float64:
+        pytest.skip("resident tiles are float32")
+    B = 5
+    H, g, A, l, u, xs = _badly_scaled(B, n, n_eq, n_ineq, seed0=90)
+    kw = dict(eps_abs=1e-5 if prec == torch.float64 else 1e-4, max_iter=20000, scaling=10)
+    m = _solver(H, g, A, l, u, precision=prec, kernel=kernel, **kw)
+    r = m.solve()
+    x, z, y = _np(r.x), _np(r.z), _np(r.y)
+    it, obj = r.info.iter.cpu().numpy().copy(), _np(r.info.obj_val)
+    ref = O.solve_batch(H, g, A, l, u, form="factored", **kw)
+    assert list(r.info.status) == ref["status"] and all(s == "solved" for s in ref["status"])
+    if prec == torch.float64:
+        assert np.array_equal(it, ref["iter"])
+    else:
+        assert np.all(np.abs(it - ref["iter"]) <= 50)
+    same = it == ref["iter"]
+    sx = np.abs(ref["x"]).max(axis=1, keepdims=True)                  # per instance: the variables span 4 decades
+    np.testing.assert_allclose(x[same] / sx[same], ref["x"][same] / sx[same], rtol=0, atol=tol)
+    np.testing.assert_allclose(obj[same], ref["obj_val"][same], rtol=max(tol, 1e-5) * 10, atol=tol)
+    # primal feasibility of the UN-scaled outputs in the caller's space
+    Ax = np.einsum("bmn,bn->bm", A, x)
+    rown = np.abs(A).max(axis=2)
+    assert np.all(Ax >= l - 5e-2 * rown * np.abs(x).max()) and np.all(Ax <= u + 5e-2 * rown * np.abs(x).max())
+    np.testing.assert_allclose(z / np.maximum(1.0, np.abs(Ax)), Ax / np.maximum(1.0, np.abs(Ax)), atol=5e-2)
+    # state round trip in caller space, warm start from the solution: first check
+    st, ri = m.get_state()
+    st = _np(st)
+    np.testing.assert_allclose(st[:, :n], x, rtol=1e-5, atol=1e-9)
+    m2 = _solver(H, g, A, l, u, precision=prec, kernel=kernel, **kw)
+    m2.warm_start(x=x, z=z, lam=y, rho=float(m.layers.rhos[int(ri[0])]))
+    r2 = m2.solve()
+    assert float(r2.info.iter.double().mean()) < 0.6 * it.mean()
+    # update(g) goes through the scaling as well: compare with a fresh oracle on the new g
+    g2 = g * 1.1
+    m.update(g=g2)
+    r3 = m.solve()
+    ref3 = O.solve_batch(H, g2, A, l, u, form="factored", eps_abs=1e-9, max_iter=50000, scaling=10)
+    np.testing.assert_allclose(_np(r3.x) / sx, ref3["x"] / sx, rtol=0, atol=50 * tol)
+    with pytest.raises(_cabi.RqpError):
+        m.update(Hx=H)                                                # new matrices would change D, E: refused, set up again
+
+
+def test_scaling_helps_badly_scaled_problems():
+    """Why the option exists: on a badly scaled batch the un-scaled ADMM needs far more iterations."""
+    H, g, A, l, u, xs = _badly_scaled(16, 20, 5, 30, seed0=300)
+    it = {}
+    for sc in (0, 10):
+        m = _solver(H, g, A, l, u, precision=torch.float64, eps_abs=1e-5, max_iter=40000, scaling=sc)
+        r = m.solve()
+        it[sc] = float(r.info.iter.double().mean())
+        if sc:
+            assert all(s == "solved" for s in r.info.status)
+            np.testing.assert_allclose(_np(r.x) / np.abs(xs).max(axis=1, keepdims=True),
+                                       xs / np.abs(xs).max(axis=1, keepdims=True), atol=5e-3)
+    assert it[10] < 0.7 * it[0]
+
+
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kernel", ["generic", "wave", "resident", "mfma"])
+def test_infeasibility_certificates(prec, kernel):
+    """check_infeasibility (C-ABI rqp_settings): OSQP certificates.  The streaming kernel tests them at every check (same exit
+    as the oracle); the register-resident / MFMA kernels run their budget and a certificate pass labels them afterwards."""
+    if kernel in ("resident", "mfma") and prec == torch.float64:
+        pytest.skip("float32 kernels")
+    n, m_ = 6, 9
+    rs = np.random.RandomState(4)
+    Mx = rs.randn(n, n)
+    H = Mx.T @ Mx + np.eye(n)
+    A = np.vstack([np.eye(n), rs.randn(m_ - n, n)])
+    A[n] = A[0]                                                       # row n repeats x_0
+    B = 4
+    g = rs.randn(B, n)
+    l = np.tile(np.r_[-np.ones(n), -2 * np.ones(m_ - n)], (B, 1))
+    u = np.tile(np.r_[np.ones(n), 2 * np.ones(m_ - n)], (B, 1))
+    # instances 1 and 3: x_0 <= 1 (row 0) against x_0 >= 3 (row n) -> primal infeasible; 0 and 2 stay feasible
+    for b in (1, 3):
+        l[b, n], u[b, n] = 3.0, np.inf
+    kw = dict(check_infeasibility=True, max_iter=400)
+    mdl = _solver(H, g, A, l, u, precision=prec, kernel=kernel, **kw)
+    r = mdl.solve()
+    ref = O.solve_batch(H, g, A, l, u, form="factored", **kw)
+    assert ref["status"] == ["solved", "primal_infeasible", "solved", "primal_infeasible"]
+    assert list(r.info.status) == ref["status"]
+    it = r.info.iter.cpu().numpy()
+    if kernel == "generic":
+        assert np.all(it[[1, 3]] < 400)                              # early exit at the check where the certificate holds
+        if prec == torch.float64:
+            assert np.array_equal(it, ref["iter"])
+    else:
+        assert np.all(it[[1, 3]] == 400)                             # labelled after the budget is spent
+    assert np.array_equal(it[[0, 2]], ref["iter"][[0, 2]]) or prec == torch.float32
+    # dual infeasible (unbounded below): zero curvature along x_0, cost pushes it to +inf, no upper bound
+    H2 = H.copy()
+    H2[0, :] = 0.0
+    H2[:, 0] = 0.0
+    A2 = np.eye(n)
+    g2 = rs.randn(B, n)
+    g2[:, 0] = -1.0
+    l2 = -np.ones((B, n))
+    u2 = np.ones((B, n))
+    u2[:, 0] = np.inf
+    mdl2 = _solver(H2, g2, A2, l2, u2, precision=prec, kernel=kernel, **kw)
+    r2 = mdl2.solve()
+    ref2 = O.solve_batch(H2, g2, A2, l2, u2, form="factored", **kw)
+    assert ref2["status"] == ["dual_infeasible"] * B
+    assert list(r2.info.status) == ref2["status"]
+    # off (the default): the reference's behaviour -- the budget is spent, "max_iters_reached"
+    mdl3 = _solver(H, g, A, l, u, precision=prec, kernel=kernel, max_iter=100)
+    assert list(mdl3.solve().info.status)[1] == "max_iters_reached"
+    # warm_starting=False + certificate pass: the state the pass needed is cleared afterwards
+    mdl4 = _solver(H, g, A, l, u, precision=prec, kernel=kernel, warm_starting=False, **kw)
+    mdl4.solve()
+    st, ri = mdl4.get_state()
+    assert float(st.abs().max()) == 0.0 and int(ri.min()) == int(ri.max()) == 7
+
+
+@pytest.mark.parametrize("kernel", ["generic", "wave", "resident"])
+def test_nan_status(kernel):
+    """A NaN in the data poisons the residuals: the reference keeps iterating and reports max_iters_reached with NaN
+    residuals (Q17); the build labels it nan_detected (status code 2) -- same loop control, only the label differs."""
+    H, g, A, l, u, _ = utils.rand_qp_batch(3, 12, 3, 17, seed0=5, feasible=True)
+    g[1, 4] = np.nan
+    m = _solver(H, g, A, l, u, precision=torch.float32, kernel=kernel, max_iter=75)
+    r = m.solve()
+    st = list(r.info.status)
+    assert st[1] == "nan_detected" and st[0] != "nan_detected" and st[2] != "nan_detected"
+    assert int(r.info.iter[1]) == 75 and bool(torch.isnan(r.info.pri_res[1]) | torch.isnan(r.info.dua_res[1]))
+    ref = O.solve_batch(H, g, A, l, u, form="factored", max_iter=75)
+    assert ref["status"][1] == "nan_detected" and ref["iter"][1] == 75
