@@ -65,6 +65,7 @@ class ReLU_QP(object):
         # ordered on that stream; times read 0) -- closed-loop drivers keep the GPU busy instead of the host waiting.
         self.synchronous = True
         self.last_kernel_time = None
+        self._shards = None           # setup(devices=[...]): one child solver per device (reluqp/multidevice.py)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -94,6 +95,9 @@ class ReLU_QP(object):
         self._destroy()
 
     def _destroy(self):
+        if getattr(self, "_shards", None):
+            self._shards.destroy()
+            self._shards = None
         if getattr(self, "_h", None):
             try:
                 _cabi.load().rqp_destroy(self._h)
@@ -124,7 +128,8 @@ class ReLU_QP(object):
               eps_prim_inf=1e-4,
               eps_dual_inf=1e-4,
               kernel="auto",
-              iterate_dtype=None):
+              iterate_dtype=None,
+              devices=None):
         """
         Setup ReLU-QP solver problem of the form
 
@@ -139,8 +144,28 @@ class ReLU_QP(object):
         ``check_infeasibility``; ``kernel`` = "auto" | "generic" | "resident" | "wave" |
         "mfma" (C-ABI rqp_dims.kernel; an explicit kernel that cannot hold the problem raises);
         ``iterate_dtype=torch.float16`` keeps the K(rho) tile of the register-resident kernels in fp16
-        (BASELINE config 5; H, A, state and residuals stay float32).
+        (BASELINE config 5; H, A, state and residuals stay float32).  ``devices=[0, 1, ...]`` splits a batch
+        contiguously over several GPUs inside this process (one handle and stream per device, results gathered on
+        devices[0]; no collective -- reluqp/multidevice.py).
         """
+        if devices is not None:
+            from reluqp.multidevice import DeviceShards
+            if not torch.cuda.is_available():
+                raise _cabi.RqpUnavailable("ReLU_QP needs a HIP device; the MI355X build has no CPU path")
+            self._destroy()
+            kw = dict(verbose=verbose, warm_starting=warm_starting, scaling=scaling, rho=rho, rho_min=rho_min, rho_max=rho_max,
+                      sigma=sigma, adaptive_rho=adaptive_rho, adaptive_rho_interval=adaptive_rho_interval,
+                      adaptive_rho_tolerance=adaptive_rho_tolerance, max_iter=max_iter, eps_abs=eps_abs,
+                      check_interval=check_interval, precision=precision, eq_tol=eq_tol, eps_rel=eps_rel,
+                      check_infeasibility=check_infeasibility, eps_prim_inf=eps_prim_inf, eps_dual_inf=eps_dual_inf,
+                      kernel=kernel, iterate_dtype=iterate_dtype)
+            self._shards = DeviceShards(ReLU_QP, list(devices), H, g, A, l, u, kw)
+            first = self._shards.children[0]
+            self.settings, self.QP, self.layers, self._rhos = first.settings, first.QP, first.layers, first._rhos
+            self.rho_ind = first.rho_ind
+            self.kernel = self._shards.kernel
+            self.results.info.setup_time = max(c.results.info.setup_time for c in self._shards.children)
+            return None
         device = _default_device() if device is None else torch.device(device)
         if precision not in (torch.float32, torch.float64):
             raise ValueError("precision must be torch.float32 or torch.float64")
@@ -200,6 +225,8 @@ class ReLU_QP(object):
         """
         Update ReLU-QP problem arguments (reference reluqpth.py:159-183; numpy or torch, Q9)
         """
+        if self._shards:
+            return self._shards.update(g=g, l=l, u=u, Hx=Hx, Ax=Ax)
         self._need_setup()
         lib = _cabi.load()
         qp = self.QP
@@ -274,6 +301,8 @@ class ReLU_QP(object):
         It is possible to change: 'max_iter', 'eps_abs', 'verbose', 'check_interval'
         (reference reluqpth.py:185-199; the whitelist typo "eps_ab" is tolerated, Q8)
         """
+        if self._shards:
+            return self._shards.update_settings(**kwargs)
         self._need_setup()
         for key, value in kwargs.items():
             if key == "eps_ab":
@@ -293,6 +322,8 @@ class ReLU_QP(object):
         Solve QP Problem (reference reluqpth.py:201-249 + update_results :278-305):
         one kernel launch for the whole batch, synchronised before returning.
         """
+        if self._shards:
+            return self._solve_shards()
         self._need_setup()
         lib = _cabi.load()
         st, qp = self.settings, self.QP
@@ -371,6 +402,24 @@ class ReLU_QP(object):
         info.run_time = run_time
         info.solve_time = info.update_time + run_time
 
+    def _solve_shards(self):
+        """devices=[...]: every shard's launch is enqueued on its own device / stream, then gathered on devices[0]."""
+        import time
+        t0 = time.perf_counter()
+        o = self._shards.solve()
+        run_time = time.perf_counter() - t0
+        info, prec = self.results.info, self.settings.precision
+        self.results.x, self.results.z, self.results.y = o["x"], o["z"], o["y"]
+        self.results.lam = self.results.y
+        info.iter, info.status_code, info.status, info.rho_ind = o["it"], o["sc"], None, o["ri"]
+        info.pri_res, info.dua_res = o["pri"].to(prec), o["dua"].to(prec)
+        info.rho_estimate, info.obj_val = o["rho"].to(prec), o["obj"].to(prec)
+        self.rho_ind = o["ri"]
+        self.x, self.z, self.lam = self.results.x, self.results.z, self.results.y
+        info.run_time = run_time
+        info.solve_time = info.update_time + run_time
+        return self.results
+
     def _rho_ind0(self):
         return int(np.argmin(np.abs(self._rhos.cpu().numpy() - self.settings.rho)))
 
@@ -380,6 +429,8 @@ class ReLU_QP(object):
         Warm start primal or dual variables, lagrange multipliers, and rho
         (reference reluqpth.py:251-276; values are written into the iterate, Q6 fixed)
         """
+        if self._shards:
+            return self._shards.warm_start(x=x, z=z, lam=lam, rho=rho)
         self._need_setup()
         qp = self.QP
         lead = (qp.batch,) if qp.batched else ()
@@ -399,6 +450,8 @@ class ReLU_QP(object):
         """
         Clear primal and dual variables and reset rho index (reference reluqpth.py:324-333)
         """
+        if self._shards:
+            return self._shards.clear_primal_dual()
         self._need_setup()
         with torch.cuda.device(self.settings.device):
             _cabi.check(self._h, _cabi.load().rqp_clear_primal_dual(self._h, self._stream()),
@@ -416,6 +469,8 @@ class ReLU_QP(object):
 
     def get_state(self):
         """(output, rho_ind): ``output`` = [x; z; lam] as the reference's ``ReLU_QP.output``."""
+        if self._shards:
+            return self._shards.get_state()
         self._need_setup()
         st, qp = self.settings, self.QP
         B, n, m = qp.batch, qp.nx, qp.nc
@@ -450,6 +505,8 @@ class ReLU_QP(object):
         return out[0, 0], out[1, 0], out[2, 0], out[3, 0]
 
     def _need_setup(self):
+        if self._shards:
+            raise RuntimeError("not available with devices=[...]: call it on a shard (model._shards.children[i])")
         if self._h is None:
             raise RuntimeError("ReLU_QP.setup() must be called first")
 

@@ -484,3 +484,38 @@ def test_nan_status(kernel):
     assert int(r.info.iter[1]) == 75 and bool(torch.isnan(r.info.pri_res[1]) | torch.isnan(r.info.dua_res[1]))
     ref = O.solve_batch(H, g, A, l, u, form="factored", max_iter=75)
     assert ref["status"][1] == "nan_detected" and ref["iter"][1] == 75
+
+
+# ------------------------------------------------------------------- devices=[...]
+@pytest.mark.parametrize("shared", [False, True])
+def test_devices_list_splits_the_batch(shared):
+    """setup(devices=[0, 0, 0]): three shards (one handle + stream each; on this one-GPU box all on device 0), results
+    gathered in batch order -- bit-identical to the single-handle solve; update / warm_start / get_state go to the shards."""
+    B, n, n_eq, n_ineq = 50, 20, 5, 30                                # 50 = 17 + 17 + 16: ragged split
+    if shared:
+        H, g0, A, l0, u0, _ = utils.rand_qp(n, n_eq, n_ineq, seed=5, compute_sol=False, feasible=True)
+        qs = [utils.update_qp(H, A, n_eq, n_ineq, seed=50 + b, compute_sol=False, feasible=True) for b in range(B)]
+        g, l, u = (np.stack([q[i] for q in qs]) for i in (1, 3, 4))
+    else:
+        H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=11, feasible=True)
+    one = _solver(H, g, A, l, u, precision=torch.float32)
+    r1 = one.solve()
+    x1, it1, y1 = r1.x.clone(), r1.info.iter.clone(), r1.y.clone()
+    import reluqp.reluqpth as reluqpth
+    multi = reluqpth.ReLU_QP()
+    multi.setup(H, g, A, l, u, precision=torch.float32, devices=[0, 0, 0])
+    assert [sz for _, sz in multi._shards.ranges] == [17, 17, 16]
+    rm = multi.solve()
+    assert torch.equal(rm.x, x1) and torch.equal(rm.info.iter, it1) and torch.equal(rm.y, y1)
+    assert list(rm.info.status) == list(r1.info.status)
+    g2 = g * 0.9
+    one.update(g=g2)
+    multi.update(g=g2)
+    assert torch.equal(multi.solve().x, one.solve().x)
+    sm, rim = multi.get_state()
+    s1, ri1 = one.get_state()
+    assert torch.equal(sm, s1) and torch.equal(rim, ri1)
+    multi.clear_primal_dual()
+    assert float(multi.get_state()[0].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        reluqpth.ReLU_QP().setup(H if shared else H[0], g[0], A if shared else A[0], l[0], u[0], devices=[0])   # un-batched
