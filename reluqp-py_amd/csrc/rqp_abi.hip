@@ -82,6 +82,7 @@ void free_ws(rqp_handle* h) {
     h->is_setup = false;
     h->order_valid = false;
     h->resident = false;
+    h->resident64 = false;
     h->use_mfma = false;
     h->use_wave = false;
     h->kernel_name = "generic";
@@ -91,6 +92,7 @@ hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) 
     if (h->use_mfma && a.mode == 0) return rqp_launch_solve_mfma(h, a, s);
     if (h->use_wave && a.mode == 0) return rqp_launch_solve_wave(h, a, s);
     if (h->resident) return rqp_launch_solve_res2(h, a, s);
+    if (h->resident64) return rqp_launch_solve_res64(h, a, s);
     return rqp_launch_solve_generic(h, a, s);
 }
 
@@ -147,14 +149,15 @@ int select_kernels(rqp_handle* h) {
         if (req != RQP_KERNEL_RESIDENT)
             return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320)");
     }
-    h->resident = h->use_wave = h->use_mfma = false;
+    h->resident = h->resident64 = h->use_wave = h->use_mfma = false;
     h->kernel_name = "generic";
     switch (req) {
         case RQP_KERNEL_GENERIC:
             break;
         case RQP_KERNEL_RESIDENT:
-            if (!rqp_res2_fits(h)) return fail_unsupported(h, "kernel=resident: needs float32, n <= 104, m <= 320");
-            h->resident = true;
+            if (rqp_res2_fits(h)) h->resident = true;
+            else if (rqp_res64_fits(h)) h->resident64 = true;
+            else return fail_unsupported(h, "kernel=resident: needs n <= 104, m <= 320");
             break;
         case RQP_KERNEL_WAVE:
             if (!rqp_wave_fits(h)) return fail_unsupported(h, "kernel=wave: needs n <= 32, m <= 64 (float32 also n <= 32, m <= 128 and 56 < n <= 64, m <= 128)");
@@ -178,6 +181,8 @@ int select_kernels(rqp_handle* h) {
                 h->use_wave = true;
             else if (rqp_res2_fits(h))
                 h->resident = true;
+            else if (rqp_res64_fits(h))      // float64 (the reference's default precision) at the headline sizes
+                h->resident64 = true;
         }
     }
     // iterate / residuals modes of an MFMA or wave handle run on the resident tile when one fits, else on the streaming kernel
@@ -186,6 +191,7 @@ int select_kernels(rqp_handle* h) {
     if (h->use_mfma) h->kernel_name = "mfma";
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
+    else if (h->resident64) h->kernel_name = "resident64";
     return RQP_OK;
 }
 
@@ -208,6 +214,7 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
         }
         HIP_TRY(h, rqp_launch_pack_res2(h, s));
     }
+    if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
         if (!h->W1img) {
             HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
@@ -331,7 +338,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
-    if (!h->use_mfma && h->B >= 4 * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
+    if (!h->use_mfma && h->B >= (h->resident64 ? 2 : 4) * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));
     }
@@ -460,7 +467,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     }
     // Infeasibility certificates: the streaming kernel tests them at every check; the register-resident / MFMA kernels
     // keep their loops untouched and a mode-3 pass of the streaming kernel examines the instances that ran out of iterations.
-    const bool post_cert = h->st.check_infeasibility && a.info.status && (h->use_mfma || h->use_wave || h->resident);
+    const bool post_cert = h->st.check_infeasibility && a.info.status && (h->use_mfma || h->use_wave || h->resident || h->resident64);
     if (post_cert) a.keep_state = 1;
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
     if (post_cert) {

@@ -47,6 +47,7 @@ struct rqp_handle {
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
     float* Kscale = nullptr;      // [nmat][nrho] power-of-two scale of the fp16 K tile (tile_dtype = RQP_TILE_F16)
     bool resident = false;        // rqp_resident2.hip: A, K in VGPRs (solve, iterate and residuals modes)
+    bool resident64 = false;      // rqp_res64.hip: the float64 resident kernel (n <= 104, m <= 320), all modes
     bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
@@ -132,6 +133,10 @@ bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+
+bool rqp_res64_fits(const rqp_handle* h);
+hipError_t rqp_prepare_res64(const rqp_handle* h);
+hipError_t rqp_launch_solve_res64(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 bool rqp_wave_fits(const rqp_handle* h);
 hipError_t rqp_launch_solve_wave(const rqp_handle* h, const SolveArgs& a, hipStream_t s);

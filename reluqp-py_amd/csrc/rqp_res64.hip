@@ -1,0 +1,395 @@
+// rqp_res64.hip -- RESIDENT ADMM kernel in FLOAT64 (the reference's default -- and only working -- precision,
+// SURVEY.md Q2) for n <= 104, m <= 320: the sizes of the headline workload (n = 100, m = 300).
+// Same recurrence, checks and semantics as k_admm_generic<double> (rqp_admm.hip; reference
+// ReLU-QP-py/reluqp/reluqpth.py:201-249, statement in oracle/reluqp_oracle.py:forward_refine); that kernel streams
+// Ht, A, K_j, At from L2/HBM every iteration (640 KB per instance-iteration in float64: HBM-bound).  Here one
+// 512-thread workgroup = one QP = one CU, and A (240 KB) and K_j (80 KB) live in the CU's 512 KB register file for the
+// whole solve; H (84.5 KB) sits in LDS; HBM is touched once per solve and per rho move.
+//
+//   wave w (of 8) owns the column block [13 w, 13 w + 13) of A for ALL rows, and rows [13 w, 13 w + 13) of K:
+//   A' nu : lane l holds rows 5 l .. 5 l + 4 of the block (5 x 13 doubles).  Its 13 partial column sums -- plus the H rows
+//           l and l + 64 of the same columns read from LDS: d = [A; H]' [nu; x] + g, H symmetric -- are transposed through a
+//           per-wave LDS slab and summed by 52 lanes (13 columns x 4 quarters), then two shuffle levels.
+//   K d   : lane (rr = l >> 2, cc = l & 3) holds K[13 w + rr][26 cc .. 26 cc + 25]; reduce over cc by two shuffle levels;
+//           lanes cc == 0, rr < 13 own x and dx of column 13 w + rr (float64 registers).
+//   A dx  : needs only the wave's own 13 dx values; the 8 per-wave partial row sums meet in LDS and are added in fixed
+//           order by the row's owner thread (row i <-> thread i), which keeps z, lam, A x of its row in registers.
+// 3 barriers per iteration.  182 float64 FMAs per lane and iteration: float64 VALU-bound.
+#include <type_traits>
+
+#include "rqp_common.h"
+
+namespace {
+
+constexpr int R64_NT = 512, R64_NW = 8, R64_CW = 13, R64_RL = 5, R64_N = 104, R64_M = 320, R64_KC = 26;
+constexpr int R64_RS = 66;                         // stride (doubles) of a column's 64 lane partials in the reduce slab
+constexpr size_t r64_lds_doubles() {
+    return (size_t)R64_N * R64_N                   // Hs [col][row]
+           + (size_t)R64_NW * R64_CW * R64_RS      // reduce slabs; the A dx partials part[8][320] alias their start
+           + 3 * R64_M + 4 * R64_N + 64 + 16;      // nu, l, u | d | dx | x | H x | reductions | check scalars
+}
+
+template <typename U>
+__device__ __forceinline__ U tmx(U a, U b) {       // torch.max / norm(inf): NaN propagates
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+
+}   // namespace
+
+__global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
+    constexpr int NT = R64_NT, NW = R64_NW, CW = R64_CW, RL = R64_RL, N = R64_N, M = R64_M, KC = R64_KC, RS = R64_RS;
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    double* Hs = sm64;                             // [N][N]: Hs[col * N + row]
+    double* slab = Hs + N * N;                     // [NW][CW][RS]
+    double* part = slab;                           // [NW][M]  (alias: the slabs are dead between the K product and the next A' nu)
+    double* nuL = slab + NW * CW * RS;             // [M]
+    double* loL = nuL + M;                         // [M] l  (row bounds wait in LDS: the register file is full of A and K)
+    double* hiL = loL + M;                         // [M] u
+    double* dL = hiL + M;                          // [N]
+    double* dxL = dL + N;                          // [N]
+    double* xL = dxL + N;                          // [N]
+    double* hxL = xL + N;                          // [N] H x of the last check (objective at the exit)
+    double* red = hxL + N;                         // [64]
+    double* stat = red + 64;                       // [16] scalars of the last check: pri, dua, rho estimate, scales (they are
+                                                   //      read again only at the next check / the exit: LDS, not registers)
+    static_assert(NW * M <= NW * CW * RS, "part aliases the reduce slabs");
+
+    const int n = a.n, m = a.m, ldn = a.ldn;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int rr = lane >> 2, cc = lane & 3;
+    const double* A = (const double*)a.A + (size_t)b * a.sA;
+    const double* Ht = (const double*)a.Ht + (size_t)b * a.sH;
+    const double* Kb = (const double*)a.K + (size_t)b * a.sK;
+
+    // ---- matrices: A, K_j -> registers ; H -> LDS (each element read from HBM once per solve)
+    double ar[RL][CW];
+#pragma unroll
+    for (int r = 0; r < RL; ++r)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int row = RL * lane + r, col = CW * wave + c;
+            ar[r][c] = (row < m && col < n) ? A[(size_t)row * ldn + col] : 0.0;
+        }
+    for (int i = tid; i < N * N; i += NT) {
+        const int col = i / N, row = i % N;
+        Hs[i] = (row < n && col < n) ? Ht[(size_t)col * ldn + row] : 0.0;      // Ht = sym(H): H[row][col] = Ht[col][row]
+    }
+    int ri = a.rho_ind[b];
+    double kr[KC];
+    auto load_K = [&](int j) {
+        const int krow = CW * wave + rr;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int col = KC * cc + c;
+            kr[c] = (rr < CW && krow < n && col < n) ? Kb[((size_t)j * n + krow) * ldn + col] : 0.0;
+        }
+    };
+    load_K(ri);
+
+    // ---- state.  Row i <-> thread i (i < M): z, lam, A x, bounds, rho in registers.  Column 13 w + rr <-> lane cc == 0.
+    const bool rown = tid < M, rin = tid < m;
+    double zt = 0.0, z = 0.0, lam = 0.0, rv = 1.0, inv = 1.0;
+    if (rin) {
+        z = a.z[(size_t)b * m + tid];
+        lam = a.lam[(size_t)b * m + tid];
+    }
+    if (rown) {
+        loL[tid] = rin ? ((const double*)a.l)[(size_t)b * m + tid] : 0.0;
+        hiL[tid] = rin ? ((const double*)a.u)[(size_t)b * m + tid] : 0.0;
+    }
+    auto set_rho = [&](int j) {
+        rv = a.rhos[j] * (rin ? ((const double*)a.c)[(size_t)b * m + tid] : 1.0);
+        inv = 1.0 / rv;
+    };
+    set_rho(ri);
+    const int xcol = CW * wave + rr;
+    const bool xown = cc == 0 && rr < CW;
+    const bool xin = xown && xcol < n;
+    double x = xin ? a.x[(size_t)b * n + xcol] : 0.0;
+    const double gx = xin ? ((const double*)a.g)[(size_t)b * n + xcol] : 0.0;
+    if (xown) {
+        xL[xcol] = x;
+        dxL[xcol] = x;                             // start pass: A x of the incoming state through the A dx product
+    }
+    if (rown) nuL[tid] = 0.0;
+    __syncthreads();
+
+    // ---- products ------------------------------------------------------------------------------------------------
+    // wave partial of A v over the wave's 13 columns -> part[wave][row]
+    auto prod_A = [&](const double* v) {
+        double vc[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) vc[c] = v[CW * wave + c];
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) s = fma(ar[r][c], vc[c], s);
+            part[wave * M + RL * lane + r] = s;
+        }
+    };
+    // [USE_A: A' w] + [USE_H: H xL] for the wave's own columns; lanes (c = lane >> 2 < 13, cc == 0) return the column sum
+    auto prod_At = [&](bool use_a, bool use_h, const double* w) -> double {
+        double* sl = slab + (size_t)wave * CW * RS;
+        double wr[RL];
+        if (use_a) {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) wr[r] = w[RL * lane + r];
+        }
+        const double x0 = use_h ? xL[lane] : 0.0;                      // lane < 64 <= N
+        const double x1 = (use_h && lane + 64 < N) ? xL[lane + 64] : 0.0;
+        // columns in two chunks (7 + 6 accumulators live instead of 13: the register file is full of A and K)
+        auto chunk = [&](auto c0c, auto c1c) __attribute__((always_inline)) {
+            constexpr int C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
+            double cs[C1 - C0];
+#pragma unroll
+            for (int c = C0; c < C1; ++c) cs[c - C0] = 0.0;
+            if (use_a) {
+#pragma unroll
+                for (int r = 0; r < RL; ++r)
+#pragma unroll
+                    for (int c = C0; c < C1; ++c) cs[c - C0] = fma(ar[r][c], wr[r], cs[c - C0]);
+            }
+            if (use_h) {
+#pragma unroll
+                for (int c = C0; c < C1; ++c) {
+                    const double* hc = Hs + (size_t)(CW * wave + c) * N;
+                    cs[c - C0] = fma(hc[lane], x0, cs[c - C0]);
+                    if (lane + 64 < N) cs[c - C0] = fma(hc[lane + 64], x1, cs[c - C0]);
+                }
+            }
+#pragma unroll
+            for (int c = C0; c < C1; ++c) sl[c * RS + lane] = cs[c - C0];
+        };
+        chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
+        chunk(std::integral_constant<int, 7>{}, std::integral_constant<int, CW>{});
+        // transpose through the wave's slab: 64 partials per column -> lane (c, q) adds a quarter, two shuffle levels finish
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double s = 0.0;
+        if (rr < CW) {
+            const double* src = sl + rr * RS + 16 * cc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += src[k];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        return s;
+    };
+    // lanes cc == 0 get sum_c K[13 w + rr][c] v[c]
+    auto prod_K = [&](const double* v) -> double {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) s = fma(kr[c], v[KC * cc + c], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        return s;
+    };
+    // row update.  do_a: A x += sum of the 8 wave partials; z = clamp(A x + lam / rho).  do_b: lam_hat, nu of the NEXT iteration.
+    auto row_pass = [&](bool init, bool do_a, bool do_b) {
+        if (!rown) return;
+        if (init || do_a) {
+            double s = part[tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += part[w * M + tid];
+            zt = (init ? 0.0 : zt) + s;
+        }
+        if (do_a) {
+            const double lo = loL[tid], hi = hiL[tid];
+            const double v = zt + lam * inv;
+            z = v;                                                    // torch.clamp: NaN stays NaN
+            if (v < lo) z = lo;
+            if (v > hi) z = hi;
+        }
+        if (do_b) {
+            const double pr = zt - z;
+            const double lh = lam + rv * pr;
+            lam = lh;
+            nuL[tid] = lh + rv * pr;
+        }
+    };
+
+    if (tid == 0) {
+        stat[0] = 0.0;                                                // pri
+        stat[1] = 0.0;                                                // dua
+        stat[2] = (a.mode == 2) ? a.rho_in : a.rhos[ri];              // carried rho estimate, reluqpth.py:211
+    }
+    bool converged = false;
+    int iters = 0;
+    const int kmax = (a.mode == 2) ? 0 : a.max_iter;
+
+    // A x of the incoming state
+    prod_A(dxL);
+    __syncthreads();
+    row_pass(true, false, kmax > 0);
+
+    // compute_residuals (reluqpth.py:307-318) on the current state; leaves (H x)[col] of the column owners in hxv
+    // updates stat[0..4] = pri, dua, rho estimate (carried, Q4), scale of pri, scale of dua; ends with a barrier
+    auto residuals = [&]() {
+        double v[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (rown) {
+            nuL[tid] = lam;
+            v[0] = fabs(zt - z);
+            v[1] = fabs(zt);
+            v[2] = fabs(z);
+        }
+        __syncthreads();
+        const double t3 = prod_At(true, false, nuL);                  // A' lam
+        __syncthreads();                                              // (slab reuse)
+        const double t2 = prod_At(false, true, nuL);                  // H x
+        if (xown) {
+            hxL[xcol] = t2;
+            v[3] = fabs(t2 + t3 + gx);
+            v[4] = fabs(t2);
+            v[5] = fabs(t3);
+            v[6] = fabs(gx);
+        }
+#pragma unroll
+        for (int e = 0; e < 7; ++e)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v[e] = tmx(v[e], __shfl_xor(v[e], off, 64));
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int e = 0; e < 7; ++e) red[wave * 8 + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            double r = red[e];
+            for (int w = 1; w < NW; ++w) r = tmx(r, red[w * 8 + e]);
+            v[e] = r;
+        }
+        if (tid == 0) {
+            const double sp = tmx(v[1], v[2]), sd = tmx(tmx(v[4], v[5]), v[6]);
+            const double num = v[0] / sp;                             // :315
+            const double den = v[3] / sd;                             // :316
+            double est = stat[2] * sqrt(num / den);                   // :317
+            if (est < a.rho_min) est = a.rho_min;                     // torch.clamp: NaN stays NaN
+            if (est > a.rho_max) est = a.rho_max;
+            stat[0] = v[0];
+            stat[1] = v[3];
+            stat[2] = est;
+            stat[3] = sp;
+            stat[4] = sd;
+        }
+        __syncthreads();
+    };
+
+    int to_chk = a.check_interval;
+    for (int k = 1; k <= kmax; ++k) {
+        __syncthreads();                                              // B3: nu (and x) visible
+        const double d = prod_At(true, true, nuL) + gx;               // d = H x + g + A' nu   (own columns)
+        if (xown) dL[xcol] = d;
+        __syncthreads();                                              // B1: d visible (the slabs are free: part may be written)
+        {
+            const double kd = prod_K(dL);
+            if (xown) {
+                const double dx = -kd;
+                x += dx;
+                dxL[xcol] = dx;
+                xL[xcol] = x;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // dx of this wave's columns: same-wave LDS hop
+        __builtin_amdgcn_wave_barrier();
+        prod_A(dxL);
+        __syncthreads();                                              // B2: partials and x visible
+        iters = k;
+        const bool on_grid = (--to_chk == 0);
+        if (on_grid) to_chk = a.check_interval;
+        const bool check = (a.mode == 0) && on_grid;                  // reluqpth.py:218 (Q3 fixed)
+        if (!check) {
+            row_pass(false, true, k < kmax);
+        } else {
+            row_pass(false, true, false);
+            const int ri_before = ri;
+            residuals();                                              // :220 (Q4: carried estimate)
+            const double pri = stat[0], dua = stat[1], rho_est = stat[2];
+            if (rho_est > a.rhos[ri] * a.tol && ri < a.nrho - 1)      // :223
+                ri += 1;
+            else if (rho_est < a.rhos[ri] / a.tol && ri > 0)          // :226
+                ri -= 1;
+            if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && tid == 0) {
+                double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
+                tr[0] = pri; tr[1] = dua; tr[2] = rho_est; tr[3] = (double)ri_before;
+            }
+            const double tp = a.eps_rel > 0 ? a.thr_p + a.eps_rel * stat[3] : a.thr_p;    // :233 (+ relative term, 8(f)-3)
+            const double td = a.eps_rel > 0 ? a.thr_d + a.eps_rel * stat[4] : a.thr_d;
+            if (pri < tp && dua < td) {
+                converged = true;
+                break;
+            }
+            if (ri != ri_before) {                                    // adaptive-rho "re-factor": table lookup
+                load_K(ri);
+                set_rho(ri);
+            }
+            if (k < kmax) row_pass(false, false, true);
+        }
+    }
+
+    __syncthreads();
+    if (a.mode == 1) {                                                // iterate-only: keep the state
+        if (xin) a.x[(size_t)b * n + xcol] = x;
+        if (rin) {
+            a.z[(size_t)b * m + tid] = z;
+            a.lam[(size_t)b * m + tid] = lam;
+        }
+        return;
+    }
+    if (!converged) residuals();                                      // :243 (Q11 fixed: fresh state)
+    const double pri = stat[0], dua = stat[1], rho_est = stat[2];
+
+    // objective 1/2 x'Hx + g'x (compute_J :320-322): hxL = H x of the last check
+    double jp = xown ? x * (0.5 * hxL[xcol] + gx) : 0.0;
+    for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
+    if (lane == 0) red[wave] = jp;
+    __syncthreads();
+    double obj = red[0];
+    for (int w = 1; w < NW; ++w) obj += red[w];
+
+    if (a.mode == 2) {
+        if (tid == 0) {
+            if (a.r_pri) a.r_pri[b] = pri;
+            if (a.r_dua) a.r_dua[b] = dua;
+            if (a.r_rho) a.r_rho[b] = rho_est;
+            if (a.r_obj) a.r_obj[b] = obj;
+        }
+        return;
+    }
+
+    // ---- update_results (reluqpth.py:278-305)
+    if (a.out_x && xin) ((double*)a.out_x)[(size_t)b * n + xcol] = x;
+    if (a.out_z && rin) ((double*)a.out_z)[(size_t)b * m + tid] = z;
+    if (a.out_lam && rin) ((double*)a.out_lam)[(size_t)b * m + tid] = lam;
+    if (tid == 0) {
+        if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
+        if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
+        if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
+        if (a.info.rho_ind) a.info.rho_ind[b] = ri;
+        if (a.info.pri_res) a.info.pri_res[b] = pri;
+        if (a.info.dua_res) a.info.dua_res[b] = dua;
+        if (a.info.rho_estimate) a.info.rho_estimate[b] = rho_est;
+        if (a.info.obj_val) a.info.obj_val[b] = obj;
+    }
+    const bool keep = a.warm_starting || a.keep_state;                // state + rho index persist (:304) or are cleared (:324-333)
+    if (xin) a.x[(size_t)b * n + xcol] = keep ? x : 0.0;
+    if (rin) {
+        a.z[(size_t)b * m + tid] = keep ? z : 0.0;
+        a.lam[(size_t)b * m + tid] = keep ? lam : 0.0;
+    }
+    if (tid == 0) a.rho_ind[b] = keep ? ri : a.rho_ind0;
+}
+
+bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N && h->m <= R64_M; }
+
+hipError_t rqp_prepare_res64(const rqp_handle* h) {
+    (void)h;
+    return hipFuncSetAttribute((const void*)k_admm_res64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(r64_lds_doubles() * sizeof(double)));
+}
+
+hipError_t rqp_launch_solve_res64(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+    k_admm_res64<<<h->B, R64_NT, r64_lds_doubles() * sizeof(double), s>>>(a);
+    return hipGetLastError();
+}

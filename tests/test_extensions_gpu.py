@@ -311,8 +311,6 @@ def _badly_scaled(B, n, n_eq, n_ineq, seed0):
 def test_eps_rel_matches_oracle(prec, kernel, n, n_eq, n_ineq):
     """eps_rel > 0 (C-ABI rqp_settings.eps_rel): OSQP-style thresholds eps_abs sqrt(dim) + eps_rel * scale.  Same exits as
     the oracle with the same extension; eps_rel = 0 is bit-for-bit the reference's test (every other test of this suite)."""
-    if kernel == "resident" and prec == torch.float64:
-        pytest.skip("resident tiles are float32")
     B = 6
     H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=70, feasible=True)
     kw = dict(eps_abs=1e-7, eps_rel=1e-3)
@@ -355,8 +353,6 @@ def test_ruiz_scaling_vs_oracle(prec, tol, kernel, n, n_eq, n_ineq):
     """settings.scaling = k Ruiz passes at setup (the reference's `scaling` is an unused TODO, reluqpth.py:105): the
     equilibrated problem is solved, every ABI boundary converts.  Against the oracle with the same scaling: same exits,
     same un-scaled x, z, y, objective; warm_start / get_state / update round-trip in the caller's space."""
-    if kernel == "resident" and prec == torch.float64:
-        pytest.skip("resident tiles are float32")
     B = 5
     H, g, A, l, u, xs = _badly_scaled(B, n, n_eq, n_ineq, seed0=90)
     kw = dict(eps_abs=1e-5 if prec == torch.float64 else 1e-4, max_iter=20000, scaling=10)
@@ -417,8 +413,8 @@ def test_scaling_helps_badly_scaled_problems():
 def test_infeasibility_certificates(prec, kernel):
     """check_infeasibility (C-ABI rqp_settings): OSQP certificates.  The streaming kernel tests them at every check (same exit
     as the oracle); the register-resident / MFMA kernels run their budget and a certificate pass labels them afterwards."""
-    if kernel in ("resident", "mfma") and prec == torch.float64:
-        pytest.skip("float32 kernels")
+    if kernel == "mfma" and prec == torch.float64:
+        pytest.skip("float32 kernel")
     n, m_ = 6, 9
     rs = np.random.RandomState(4)
     Mx = rs.randn(n, n)
@@ -519,3 +515,35 @@ def test_devices_list_splits_the_batch(shared):
     assert float(multi.get_state()[0].abs().max()) == 0.0
     with pytest.raises(ValueError):
         reluqpth.ReLU_QP().setup(H if shared else H[0], g[0], A if shared else A[0], l[0], u[0], devices=[0])   # un-batched
+
+
+# ------------------------------------------------------------------- float64 resident kernel (the reference's precision)
+def test_resident64_equals_streaming_float64():
+    """k_admm_res64 (A, K in registers, one CU per QP) against k_admm_generic<double> (streaming) at the headline size in the
+    reference's default precision: identical exits, iteration counts and rho indices; x, z, y to rounding (1e-9 stated:
+    same recurrence, different summation order of the matrix-vector products)."""
+    B, n, n_eq, n_ineq = 24, 100, 25, 275
+    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=800, feasible=True)
+    mr = _solver(H, g, A, l, u, precision=torch.float64)
+    mg = _solver(H, g, A, l, u, precision=torch.float64, kernel="generic")
+    assert mr.kernel == "resident64" and mg.kernel == "generic"
+    rr, rg = mr.solve(), mg.solve()
+    assert list(rr.info.status) == list(rg.info.status) and all(s == "solved" for s in rg.info.status)
+    assert torch.equal(rr.info.iter, rg.info.iter)
+    assert torch.equal(rr.info.rho_ind, rg.info.rho_ind)
+    for a_, b_, w in ((rr.x, rg.x, 1.0), (rr.z, rg.z, 1.0), (rr.y, rg.y, 100.0)):
+        np.testing.assert_allclose(_np(a_), _np(b_), rtol=0, atol=w * 1e-9 * max(1.0, float(b_.abs().max())))
+    np.testing.assert_allclose(_np(rr.info.obj_val), _np(rg.info.obj_val), rtol=1e-9)
+    np.testing.assert_allclose(_np(rr.info.pri_res), _np(rg.info.pri_res), rtol=1e-5, atol=1e-12)
+    # ragged sizes inside the tile, shared matrices, warm re-solve, max_iter off the check grid
+    H2, g0, A2, l0, u0, _ = utils.rand_qp(77, 11, 200, seed=5, compute_sol=False, feasible=True)
+    qs = [utils.update_qp(H2, A2, 11, 200, seed=50 + b, compute_sol=False, feasible=True) for b in range(6)]
+    g2, l2, u2 = (np.stack([q[i] for q in qs]) for i in (1, 3, 4))
+    ms = _solver(H2, g2, A2, l2, u2, precision=torch.float64, max_iter=130)
+    mt = _solver(H2, g2, A2, l2, u2, precision=torch.float64, max_iter=130, kernel="generic")
+    assert ms.kernel == "resident64"
+    for _ in range(2):
+        rs, rt = ms.solve(), mt.solve()
+        assert torch.equal(rs.info.iter, rt.info.iter) and list(rs.info.status) == list(rt.info.status)
+        np.testing.assert_allclose(_np(rs.x), _np(rt.x), rtol=0, atol=1e-9 * max(1.0, float(rt.x.abs().max())))
+        np.testing.assert_allclose(_np(rs.info.rho_estimate), _np(rt.info.rho_estimate), rtol=1e-6)

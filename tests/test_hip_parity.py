@@ -45,9 +45,10 @@ def _model(H, g, A, l, u, precision=torch.float64, generic=False, wave=True, ker
     m.setup(H=H, g=g, A=A, l=l, u=u, device=_dev(), precision=precision, kernel=kernel, **kw)
     if generic:
         assert m.kernel == "generic"
-    elif precision == torch.float64 and kernel == "auto":   # float64: the one-wavefront kernel for small problems, else streaming
-        small = n_ <= 32 and m_ <= 64
-        assert m.kernel == ("wave" if small else "generic")
+    elif precision == torch.float64 and kernel == "auto":   # float64: one wavefront per QP for small problems, the float64
+        small = n_ <= 32 and m_ <= 64                       # resident kernel up to n = 104, m = 320, else streaming
+        mid = n_ <= 104 and m_ <= 320
+        assert m.kernel == ("wave" if small else ("resident64" if mid else "generic"))
     return m
 
 
@@ -107,7 +108,7 @@ def test_g1_ladder_and_kernel_loaded(golden):
 
 # (precision, tolerances..., kernel request): rqp_iterate / rqp_compute_residuals (modes 1 / 2) run on the streaming kernel
 # for a wave handle and on k_admm_res2 for a resident handle -- both meet the reference's fixed-k states
-PREC_K = [p + ("auto",) for p in PREC] + [PREC[1] + ("resident",)]
+PREC_K = [p + ("auto",) for p in PREC] + [PREC[1] + ("resident",), PREC[0] + ("resident",)]
 
 
 @pytest.mark.parametrize("prec,xtol,rr,ra,kern", PREC_K)
@@ -115,7 +116,7 @@ def test_g1_iterates(golden, prec, xtol, rr, ra, kern):
     g = golden("g1_builtin.npz")
     for k, key in ((1, "state_k1"), (2, "state_k2"), (25, "state_k25")):
         m = _model(*_qp(g), precision=prec, kernel=kern)
-        assert kern == "auto" or m.kernel == "resident2"
+        assert kern == "auto" or m.kernel == ("resident2" if prec == torch.float32 else "resident64")
         s = m.iterate(k)
         np.testing.assert_allclose(_np(s), g[key], rtol=0, atol=xtol * 10 * max(1, np.abs(g[key]).max()))
     # k iterations in two calls == one call (state round-trips through HBM in float64)
@@ -243,7 +244,7 @@ def test_g5_update(golden, prec, xtol, rr, ra):
 
 # --------------------------------------------- G6: compute_residuals / compute_J
 @pytest.mark.parametrize("prec,rtol,kern", [(torch.float64, 1e-9, "auto"), (torch.float32, 2e-4, "auto"),
-                                            (torch.float32, 2e-4, "resident")])
+                                            (torch.float32, 2e-4, "resident"), (torch.float64, 1e-9, "resident")])
 def test_g6_residuals(golden, prec, rtol, kern):
     g = golden("g6_residuals.npz")
     for i in range(int(g["n_cases"])):
