@@ -29,6 +29,20 @@ constexpr size_t r64_lds_doubles() {
            + 3 * R64_M + 4 * R64_N + 64 + 16;      // nu, l, u | d | dx | x | H x | reductions | check scalars
 }
 
+// v + (v of lane ^ 1) and v + (v of lane ^ 2): quad permutes on the two 32-bit halves (DPP, no LDS round trip --
+// __shfl_xor on a double is two ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {     // sum over the 4 lanes of a quad, every lane gets it
+    v = dpp_add64<0xB1>(v);                                // quad_perm [1,0,3,2]
+    return dpp_add64<0x4E>(v);                             // quad_perm [2,3,0,1]
+}
+
 template <typename U>
 __device__ __forceinline__ U tmx(U a, U b) {       // torch.max / norm(inf): NaN propagates
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
@@ -137,9 +151,12 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
 #pragma unroll
             for (int r = 0; r < RL; ++r) wr[r] = w[RL * lane + r];
         }
+        // H rows of this lane: lane and lane + 64 (clamped: the multiplier of a row past N is 0 -- no divergent branch, so
+        // the LDS reads of a chunk can be requested together)
+        const int hr1 = (lane + 64 < N) ? lane + 64 : N - 1;
         const double x0 = use_h ? xL[lane] : 0.0;                      // lane < 64 <= N
-        const double x1 = (use_h && lane + 64 < N) ? xL[lane + 64] : 0.0;
-        // columns in two chunks (7 + 6 accumulators live instead of 13: the register file is full of A and K)
+        const double x1 = (use_h && lane + 64 < N) ? xL[hr1] : 0.0;
+        // columns in three chunks (4 + 4 + 5 accumulators live instead of 13: the register file is full of A and K)
         auto chunk = [&](auto c0c, auto c1c) __attribute__((always_inline)) {
             constexpr int C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
             double cs[C1 - C0];
@@ -156,14 +173,15 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
                 for (int c = C0; c < C1; ++c) {
                     const double* hc = Hs + (size_t)(CW * wave + c) * N;
                     cs[c - C0] = fma(hc[lane], x0, cs[c - C0]);
-                    if (lane + 64 < N) cs[c - C0] = fma(hc[lane + 64], x1, cs[c - C0]);
+                    cs[c - C0] = fma(hc[hr1], x1, cs[c - C0]);
                 }
             }
 #pragma unroll
             for (int c = C0; c < C1; ++c) sl[c * RS + lane] = cs[c - C0];
         };
-        chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
-        chunk(std::integral_constant<int, 7>{}, std::integral_constant<int, CW>{});
+        chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        chunk(std::integral_constant<int, 8>{}, std::integral_constant<int, CW>{});
         // transpose through the wave's slab: 64 partials per column -> lane (c, q) adds a quarter, two shuffle levels finish
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -173,18 +191,14 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += src[k];
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        return s;
+        return quad_sum(s);
     };
     // lanes cc == 0 get sum_c K[13 w + rr][c] v[c]
     auto prod_K = [&](const double* v) -> double {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < KC; ++c) s = fma(kr[c], v[KC * cc + c], s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        return s;
+        return quad_sum(s);
     };
     // row update.  do_a: A x += sum of the 8 wave partials; z = clamp(A x + lam / rho).  do_b: lam_hat, nu of the NEXT iteration.
     auto row_pass = [&](bool init, bool do_a, bool do_b) {
