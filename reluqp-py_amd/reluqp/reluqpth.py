@@ -330,9 +330,6 @@ class ReLU_QP(object):
         dev, B, n, m = st.device, qp.batch, qp.nx, qp.nc
         with torch.cuda.device(dev):
             timed = self.synchronous
-            if timed:
-                start, end = self._events()
-                start.record()
             xzl = torch.empty(B * (n + 2 * m), device=dev, dtype=st.precision)      # one allocation, three contiguous views
             x, z, lam = xzl[:B * n].view(B, n), xzl[B * n:B * (n + m)].view(B, m), xzl[B * (n + m):].view(B, m)
             ints = torch.empty(3, B, device=dev, dtype=torch.int32)
@@ -345,17 +342,16 @@ class ReLU_QP(object):
                              pri_res=dbls[0].data_ptr(), dua_res=dbls[1].data_ptr(),
                              rho_estimate=dbls[2].data_ptr(), obj_val=dbls[3].data_ptr(),
                              trace=trace.data_ptr() if trace is not None else None, trace_cap=cap, reserved=0)
-            if timed:
+            if timed:                    # one pair of HIP events around the launch: run_time = what the device spent
                 k0, k1 = self._events()
                 k0.record()
             _cabi.check(self._h, lib.rqp_solve(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
                                                ctypes.byref(ci), self._stream()), "rqp_solve")
             if timed:
                 k1.record()
-                end.record()
-                end.synchronize()
-                run_time = start.elapsed_time(end) / 1000.0
-                self.last_kernel_time = k0.elapsed_time(k1) / 1000.0   # the ADMM launch alone (HIP events)
+                k1.synchronize()
+                run_time = k0.elapsed_time(k1) / 1000.0
+                self.last_kernel_time = run_time                       # the ADMM launch (+ its order / un-scaling passes)
             else:                        # enqueue only: results are device tensors ordered on the current stream
                 run_time = 0.0
                 self.last_kernel_time = None
@@ -383,9 +379,9 @@ class ReLU_QP(object):
             info.status_code = ints[1]
             info.status = None            # materialised lazily from status_code (classes.Info.status)
             info.rho_ind = ints[2]
-            dp = dbls.to(prec)            # one cast for the four per-instance scalars
-            info.pri_res, info.dua_res = dp[0], dp[1]
-            info.rho_estimate, info.obj_val = dp[2], dp[3]
+            # per-instance scalars of a batch stay float64 as the kernels wrote them (no cast launch per solve)
+            info.pri_res, info.dua_res = dbls[0], dbls[1]
+            info.rho_estimate, info.obj_val = dbls[2], dbls[3]
             self.rho_ind = ints[2]
         else:
             self.results.x, self.results.z, self.results.y = x[0], z[0], lam[0]
