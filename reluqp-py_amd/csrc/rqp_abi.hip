@@ -8,7 +8,7 @@
 
 #include "rqp_common.h"
 
-#define RQP_VERSION "rqp-hip 0.1 gfx950"
+#define RQP_VERSION "rqp-hip 0.2 gfx950"
 
 namespace {
 

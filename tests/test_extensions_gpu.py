@@ -547,3 +547,31 @@ def test_resident64_equals_streaming_float64():
         assert torch.equal(rs.info.iter, rt.info.iter) and list(rs.info.status) == list(rt.info.status)
         np.testing.assert_allclose(_np(rs.x), _np(rt.x), rtol=0, atol=1e-9 * max(1.0, float(rt.x.abs().max())))
         np.testing.assert_allclose(_np(rs.info.rho_estimate), _np(rt.info.rho_estimate), rtol=1e-6)
+
+
+# ------------------------------------------------------------------- sizes beyond every resident tile
+@pytest.mark.parametrize("prec", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,n_eq,n_ineq", [(120, 30, 200), (136, 30, 250), (200, 40, 360)])
+def test_large_sizes_streaming_kernel_and_factor_fallbacks(prec, n, n_eq, n_ineq):
+    """n > 104: the streaming ADMM kernel, and the three factorisation paths behind the register-resident one -- LDS
+    Gauss-Jordan with 128 columns (n <= 128), LDS Gauss-Jordan (n*n doubles fit LDS: n <= 141), global-scratch (larger)."""
+    B = 2
+    H, g, A, l, u, xs = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=600 + n, feasible=True)
+    m = _solver(H, g, A, l, u, precision=prec)
+    assert m.kernel == "generic"
+    r = m.solve()
+    ref = O.solve_batch(H, g, A, l, u, form="factored")
+    it = r.info.iter.cpu().numpy()
+    assert list(r.info.status) == ref["status"] == ["solved"] * B
+    if prec == torch.float64:
+        assert np.array_equal(it, ref["iter"])
+        np.testing.assert_allclose(_np(r.x), ref["x"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["x"]).max()))
+        K = _np(m.layers.K(9, 1))
+        rv = O.rho_vector(float(m.layers.rhos[9]), l[1], u[1], 1e-6)
+        Kref = np.linalg.inv(H[1] + 1e-6 * np.eye(n) + A[1].T @ (rv[:, None] * A[1]))
+        np.testing.assert_allclose(K, Kref, rtol=1e-7, atol=1e-9 * np.abs(Kref).max())
+    else:
+        assert np.all(np.abs(it - ref["iter"]) <= 50)
+        same = it == ref["iter"]
+        np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0, atol=5e-5 * max(1.0, np.abs(ref["x"]).max()))
+    np.testing.assert_allclose(_np(r.x), xs, rtol=0, atol=2e-2 * max(1.0, np.abs(xs).max()))
