@@ -73,7 +73,7 @@ void free_ws(rqp_handle* h) {
     void** ptrs[] = {&h->Ht, &h->A, &h->At, &h->K, &h->g, &h->l, &h->u, &h->c, (void**)&h->G,
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
                      (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
-                     (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d,
+                     (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d, (void**)&h->cont_iter_d, (void**)&h->cont_rho_d,
                      (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -342,6 +342,13 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));
     }
+    h->handoff_cols = 0;
+    if (h->use_mfma && h->resident && (h->B + 15) / 16 <= h->ncu) {   // straggler hand-off (SolveArgs): one tile per CU at most
+        HIP_TRY(h, hipMalloc((void**)&h->cont_iter_d, (size_t)h->B * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void**)&h->cont_rho_d, (size_t)h->B * sizeof(double)));
+        h->handoff_cols = 6;    // measured on the config-3 batch: 4.7 M QP/s without, 5.0 M at 2-4, 6.2 M at 6-10, 5.5 M at 12 (tools/)
+        if (const char* e = getenv("RQP_HANDOFF_COLS")) h->handoff_cols = atoi(e);      // tuning aid (read at setup only)
+    }
     SetupArgs a = make_setup_args(h, H, g, A, l, u);
     HIP_TRY(h, rqp_launch_pack_vecs(h, a, s));
     if (h->dims.shared_mats && h->B > 1) {
@@ -469,7 +476,23 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     // keep their loops untouched and a mode-3 pass of the streaming kernel examines the instances that ran out of iterations.
     const bool post_cert = h->st.check_infeasibility && a.info.status && (h->use_mfma || h->use_wave || h->resident || h->resident64);
     if (post_cert) a.keep_state = 1;
+    const bool handoff = h->use_mfma && h->handoff_cols > 0 && a.info.status != nullptr;
+    if (handoff) {
+        a.handoff_cols = h->handoff_cols;
+        a.cont_iter = h->cont_iter_d;
+        a.cont_rho = h->cont_rho_d;
+        a.keep_state = 1;                           // the continue pass clears what warm_starting = 0 asks to clear
+    }
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
+    if (handoff) {                                  // stragglers finish on the per-instance resident kernel
+        SolveArgs c = a;
+        c.cont = 1;
+        c.handoff_cols = 0;
+        c.keep_state = post_cert ? 1 : 0;
+        c.order = nullptr;
+        c.last_iter = nullptr;
+        HIP_TRY(h, rqp_launch_solve_res2(h, c, (hipStream_t)stream));
+    }
     if (post_cert) {
         SolveArgs c = a;
         c.mode = 3;

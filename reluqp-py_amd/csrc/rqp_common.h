@@ -10,6 +10,7 @@
 
 #include "rqp_abi.h"
 
+#define RQP_STATUS_CONTINUE (-2)   // internal: handed from the MFMA kernel to the per-instance kernel mid-solve (never returned)
 #define RQP_NT 256          // threads per workgroup of the generic kernels (4 wavefronts)
 #define RQP_WAVE 64         // CDNA wavefront
 
@@ -57,6 +58,9 @@ struct rqp_handle {
     // iteration count, so the launch ends with a tail of late, long solves (14 % of the headline launch, measured).  After
     // every solve the instances are ranked by the iteration count they just needed (counting sort on the device) and the next
     // launch issues them longest-first.  Pure scheduling: results do not depend on it.  Batches of >= 4 workgroups per CU only.
+    int32_t* cont_iter_d = nullptr;   // straggler hand-off MFMA -> resident (SolveArgs)
+    double* cont_rho_d = nullptr;
+    int handoff_cols = 0;
     int32_t* order_d = nullptr;   // [B] instance of workgroup i
     int32_t* last_iter_d = nullptr;
     bool order_valid = false;
@@ -87,6 +91,13 @@ struct SolveArgs {
     int32_t* rho_ind;
     void *out_x, *out_z, *out_lam;
     rqp_info info;
+    // Straggler hand-off (shared-matrix batches with at most one tile per CU): a 16-instance MFMA tile iterates as long as
+    // its slowest member; once at most `handoff_cols` of its columns are still unsolved at a check, the tile stops and those
+    // instances finish on the per-instance resident kernel (`cont` = 1), whose iteration is ~3x shorter than a tile's.
+    int handoff_cols;         // MFMA kernel: 0 = off
+    int cont;                 // resident kernel: 1 = only instances with status RQP_STATUS_CONTINUE, resumed at cont_iter
+    int32_t* cont_iter;       // [B] iterations done at the hand-off
+    double* cont_rho;         // [B] carried rho estimate at the hand-off (Q4)
     const int32_t* order;     // workgroup -> instance (NULL: identity)
     int32_t* last_iter;       // iteration count of this solve, for the next launch's order (NULL: not recorded)
     double *r_pri, *r_dua, *r_rho, *r_obj;   // mode 2 outputs

@@ -651,13 +651,17 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     obj += rr[(g2 * 16 + j) * 8 + 7];
                 }
                 int newly = 0;
-                if (inst_i[5 * 16 + j] == 0) {
-                    const float num = q0 / nanmaxf(q1, q2);                               // :315
-                    const float den = q3 / nanmaxf(nanmaxf(q4, q5), q6);                  // :316
-                    float est = inst[0 * 16 + j] * sqrtf(num / den);                      // :317 (Q4: carried)
+                const bool alive = inst_i[5 * 16 + j] == 0;
+                float est = 0.f, num = 0.f, den = 1.f;
+                int ri = 0, id = 0, kc = 0;
+                bool conv = false, last = false;
+                if (alive) {
+                    num = q0 / nanmaxf(q1, q2);                                           // :315
+                    den = q3 / nanmaxf(nanmaxf(q4, q5), q6);                              // :316
+                    est = inst[0 * 16 + j] * sqrtf(num / den);                            // :317 (Q4: carried)
                     if (est < rmin) est = rmin;                                           // torch.clamp: NaN stays NaN
                     if (est > rmax) est = rmax;
-                    int ri = inst_i[4 * 16 + j];
+                    ri = inst_i[4 * 16 + j];
                     const int ri_before = ri;
                     if (!final_chk) {
                         if (est > rhosf[ri] * tolT && ri < a.nrho - 1) ri += 1;           // :223
@@ -665,7 +669,8 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     }
                     inst[0 * 16 + j] = est;
                     inst_i[4 * 16 + j] = ri;
-                    const int id = inst_i[2 * 16 + j], kc = k - inst_i[3 * 16 + j];       // this instance's own iteration count
+                    id = inst_i[2 * 16 + j];
+                    kc = k - inst_i[3 * 16 + j];                                          // this instance's own iteration count
                     const int chk_no = kc / a.check_interval;
                     if (!final_chk && a.info.trace && chk_no <= a.info.trace_cap) {
                         double* tr = a.info.trace + ((size_t)id * a.info.trace_cap + (chk_no - 1)) * 4;
@@ -674,11 +679,17 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                     const float er = inst[16 + 5];                                        // eps_rel (0: the reference's absolute test)
                     const float tp = er > 0.f ? thr_p + er * nanmaxf(q1, q2) : thr_p;
                     const float td = er > 0.f ? thr_d + er * nanmaxf(nanmaxf(q4, q5), q6) : thr_d;
-                    const bool conv = !final_chk && (q0 < tp && q3 < td);                 // :233
-                    const bool last = final_chk || kc >= kmax;                             // :243 max-iter fallthrough
-                    if (conv || last) {
+                    conv = !final_chk && (q0 < tp && q3 < td);                            // :233
+                    last = final_chk || kc >= kmax;                                        // :243 max-iter fallthrough
+                }
+                // straggler hand-off: few columns of the tile still iterate (and no queue refills them) -> they leave with
+                // status CONTINUE and finish on the per-instance kernel; the tile ends here
+                const bool still = alive && !conv && !last;
+                const int nact = __popcll(__ballot(still));
+                const bool hand = still && !refill && a.handoff_cols > 0 && nact <= a.handoff_cols && a.info.status != nullptr;
+                if (alive && (conv || last || hand)) {
                         float est_out = est;
-                        if (!conv && !final_chk) {       // max_iter is a multiple of check_interval: the reference runs
+                        if (!conv && !final_chk && !hand) {   // max_iter is a multiple of check_interval: the reference runs
                             // compute_residuals once more on the same state (:243), compounding the estimate again
                             est_out = est * sqrtf(num / den);
                             if (est_out < rmin) est_out = rmin;
@@ -687,6 +698,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         newly = id + 1;
                         inst_i[5 * 16 + j] = 1;
                         const size_t bj = (size_t)id;
+                        if (hand) {
+                            a.info.status[bj] = RQP_STATUS_CONTINUE;
+                            a.cont_iter[bj] = kc;
+                            a.cont_rho[bj] = (double)est;
+                        } else {
                         if (a.info.iter) a.info.iter[bj] = conv ? kc : a.max_iter;
                         if (a.info.status) a.info.status[bj] = conv ? RQP_STATUS_SOLVED : ((q0 != q0 || q3 != q3) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
                         if (a.info.rho_ind) a.info.rho_ind[bj] = ri;
@@ -694,6 +710,7 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         if (a.info.dua_res) a.info.dua_res[bj] = (double)q3;
                         if (a.info.rho_estimate) a.info.rho_estimate[bj] = (double)est_out;
                         if (a.info.obj_val) a.info.obj_val[bj] = (double)obj;
+                        }
                         a.rho_ind[bj] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
                         if (refill) {                    // this slot takes the next unsolved instance
                             const int nxt = (int)gridDim.x * 16 + atomicAdd(queue, 1);
@@ -707,7 +724,6 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                                 inst[0 * 16 + j] = rhosf[rn];
                             }
                         }
-                    }
                 }
                 inst_i[7 * 16 + j] = newly;
                 // Columns without a live instance keep iterating on garbage; give them the rho index of a live column so that

@@ -153,6 +153,22 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
     const size_t mat = (a.sA == 0) ? 0 : (size_t)b;
     const float* cg = (const float*)a.c + (size_t)b * m;
+    // continue mode (SolveArgs.cont): only the instances the MFMA kernel handed over, resumed at their iteration count
+    int k0 = 0;
+    if (a.cont) {
+        if (a.info.status[b] != RQP_STATUS_CONTINUE) {             // (uniform per workgroup)
+            if (!a.warm_starting) {                                // the first kernel kept every state for this pass: clear it
+                for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = 0.0;
+                for (int i = tid; i < m; i += NT) {
+                    a.z[(size_t)b * m + i] = 0.0;
+                    a.lam[(size_t)b * m + i] = 0.0;
+                }
+                if (tid == 0) a.rho_ind[b] = a.rho_ind0;
+            }
+            return;
+        }
+        k0 = a.cont_iter[b];
+    }
 
     // ---- matrices: A, K_j -> VGPR pairs ; H -> LDS  (each element read from HBM once per solve)
     f2 ar[RP][CQ];
@@ -437,17 +453,17 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         }
     };
 
-    float rho_est = (a.mode == 2) ? (float)a.rho_in : (float)a.rhos[ri];       // reluqpth.py:211
+    float rho_est = (a.mode == 2) ? (float)a.rho_in : (a.cont ? (float)a.cont_rho[b] : (float)a.rhos[ri]);   // reluqpth.py:211
     float pri = 0.f, dua = 0.f;
     bool converged = false;
-    int iters = 0;
+    int iters = k0;
     const float tolT = (float)a.tol;
     const int kmax = (a.mode == 2) ? 0 : a.max_iter;
 
     // ---- A x and H x of the incoming state
     prod_A(xin);
     __syncthreads();
-    row_pass(true, false, kmax > 0);
+    row_pass(true, false, kmax > k0);
 
     // ---- compute_residuals (reluqpth.py:307-318) on the current state (hx = H x valid)
     float scl_p = 0.f, scl_d = 0.f;                                    // residual scales of the last check (eps_rel)
@@ -514,8 +530,8 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     };
 
     stamp(-1);
-    int to_chk = a.check_interval;                                     // iterations until k % check_interval == 0
-    for (int k = 1; k <= kmax; ++k) {
+    int to_chk = a.check_interval - (k0 % a.check_interval);           // iterations until k % check_interval == 0
+    for (int k = k0 + 1; k <= kmax; ++k) {
         __syncthreads();                                               // B3: nu (and hg) visible
         stamp(0);
         prod_At(YES, YES, nu, dvec, true);                             // d = H x + g + A' nu   (own columns)
