@@ -343,6 +343,7 @@ class OracleQP:
         self._lu_setup = (self.l.copy(), self.u.copy())    # the equality pattern (rho x 1e3 rows) is fixed at setup (raw l, u)
         self._sc = None
         passes = 10 if st.scaling is True else int(st.scaling or 0)
+        self._raw = dict(H=self.H.copy(), A=self.A.copy(), g=self.g.copy(), l=self.l.copy(), u=self.u.copy())
         if passes > 0:                                     # build extension (8(f)-3): solve the equilibrated problem
             assert not self.quirks, "the reference has no scaling"
             D, E, c, Hs, As = ruiz_scale(self.H, self.A, passes)
@@ -390,6 +391,9 @@ class OracleQP:
         t0 = time.perf_counter()
         dt = self.settings.dtype
         sc = getattr(self, "_sc", None)
+        for k_, v_ in (("g", g), ("l", l), ("u", u)):
+            if v_ is not None:
+                self._raw[k_] = np.ascontiguousarray(v_, dtype=dt)
         if g is not None:
             self.g = np.ascontiguousarray(g, dtype=dt)
             if sc is not None:
@@ -409,11 +413,26 @@ class OracleQP:
             # defines it as: new dense H / A, the matrices of setup_matrices (:40-78) rebuilt with the
             # equality pattern of setup, state and rho index carried -- this restatement is that definition.
             assert not self.quirks, "updating Hx and Ax is not supported yet"
-            assert sc is None, "matrix updates with scaling: set up again"
             if Hx is not None:
-                self.H = np.ascontiguousarray(Hx, dtype=dt)
+                self._raw["H"] = np.ascontiguousarray(Hx, dtype=dt)
             if Ax is not None:
-                self.A = np.ascontiguousarray(Ax, dtype=dt)
+                self._raw["A"] = np.ascontiguousarray(Ax, dtype=dt)
+            self.H, self.A = self._raw["H"], self._raw["A"]
+            if sc is not None:                             # new D, E, c: vectors and state move to the new scaled space
+                D0, E0, c0 = sc
+                passes = 10 if self.settings.scaling is True else int(self.settings.scaling)
+                D, E, c, Hs, As = ruiz_scale(self.H, self.A, passes)
+                self._sc = (D, E, c)
+                self.H, self.A = Hs.astype(dt), As.astype(dt)
+                self.g = (self._raw["g"].astype(np.float64) * (c * D)).astype(dt)
+                self.l = (self._raw["l"].astype(np.float64) * E).astype(dt)
+                self.u = (self._raw["u"].astype(np.float64) * E).astype(dt)
+                n_, m_ = self.nx, self.nc
+                o = self.output.astype(np.float64)
+                o[:n_] *= D0 / D
+                o[n_:n_ + m_] *= E / E0
+                o[n_ + m_:] *= (c / c0) * (E0 / E)
+                self.output = o.astype(dt)
             self._build_matrices()
             self._acc = None
         self.info.update_time = time.perf_counter() - t0

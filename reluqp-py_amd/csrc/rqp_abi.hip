@@ -384,13 +384,25 @@ int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream) {
     if (!h) return RQP_ERR_ARG;
     if (!h->is_setup) return RQP_ERR_STATE;
     if (!H && !A) return RQP_OK;
-    if (h->st.scaling > 0)
-        return fail_unsupported(h, "rqp_update_mats with scaling: new matrices change D, E -- run rqp_setup again (state can be carried with "
-                                   "rqp_get_state / rqp_warm_start)");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->device));
     SetupArgs a = make_setup_args(h, H, nullptr, A, nullptr, nullptr);
-    return build_matrices(h, a, s);             // state, rho indices, g, l, u, c untouched
+    if (h->st.scaling <= 0) return build_matrices(h, a, s);             // state, rho indices, g, l, u, c untouched
+    // With Ruiz scaling the packed copies are D H D / E A D: a new matrix changes D, E, c, so BOTH raw matrices are needed, and
+    // the handle's vectors and state move from the old scaled space to the new one.
+    if (!H || !A) return fail_unsupported(h, "rqp_update_mats with scaling needs both H and A (the packed copies are scaled)");
+    const size_t nm = h->nmat, nD = nm * h->n, nE = nm * h->m;
+    double* old = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&old, (nD + nE + nm) * sizeof(double)));
+    hipError_t e1 = hipMemcpyAsync(old, h->Dsc, nD * sizeof(double), hipMemcpyDeviceToDevice, s);
+    hipError_t e2 = hipMemcpyAsync(old + nD, h->Esc, nE * sizeof(double), hipMemcpyDeviceToDevice, s);
+    hipError_t e3 = hipMemcpyAsync(old + nD + nE, h->csc, nm * sizeof(double), hipMemcpyDeviceToDevice, s);
+    int rc = (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) ? fail_hip(h, hipErrorUnknown, "copy of the scaling factors") : RQP_OK;
+    if (rc == RQP_OK) rc = build_matrices(h, a, s);                      // pack -> Ruiz (new D, E, c) -> gram -> factor -> images
+    if (rc == RQP_OK && rqp_launch_rescale(h, old, old + nD, old + nD + nE, s) != hipSuccess) rc = fail_hip(h, hipGetLastError(), "k_rescale");
+    (void)hipStreamSynchronize(s);                                       // `old` is freed below
+    (void)hipFree(old);
+    return rc;
 }
 
 int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void* stream) {

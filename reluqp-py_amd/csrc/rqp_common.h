@@ -127,6 +127,7 @@ hipError_t rqp_launch_state_set(const rqp_handle* h, const void* x, const void* 
                                 int rho_ind, hipStream_t s);
 hipError_t rqp_launch_state_get(const rqp_handle* h, void* x, void* z, void* lam, int32_t* rho_ind, hipStream_t s);
 hipError_t rqp_launch_ruiz(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_rescale(const rqp_handle* h, const double* D0, const double* E0, const double* c0, hipStream_t s);
 hipError_t rqp_launch_scale_vecs(const rqp_handle* h, void* g, void* l, void* u, hipStream_t s);
 hipError_t rqp_launch_scale_state(const rqp_handle* h, double* x, double* z, double* lam, hipStream_t s);
 hipError_t rqp_launch_unscale_out(const rqp_handle* h, void* x, void* z, void* lam, double* obj, hipStream_t s);

@@ -149,6 +149,40 @@ __global__ void k_unscale_out(int B, int n, int m, int shared, T* x, T* z, T* la
     if (obj) for (size_t b = tid; b < (size_t)B; b += nth) obj[b] = obj[b] / cs[shared ? 0 : b];
 }
 
+// New scaling factors after a matrix update: the handle's (already scaled) vectors and state move from the old space
+// to the new one.  g *= (c' D') / (c D);  l, u *= E' / E;  xb *= D / D';  zb *= E' / E;  lamb *= (c' / c) (E / E').
+template <typename T>
+__global__ void k_rescale(int B, int n, int m, int shared, T* g, T* l, T* u, double* x, double* z, double* lam,
+                          const double* __restrict__ D0, const double* __restrict__ E0, const double* __restrict__ c0,
+                          const double* __restrict__ D1, const double* __restrict__ E1, const double* __restrict__ c1) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < (size_t)B * n; i += nth) {
+        const size_t b = i / n, mt = shared ? 0 : b, k = mt * n + i % n;
+        g[i] = (T)((double)g[i] * ((c1[mt] * D1[k]) / (c0[mt] * D0[k])));
+        x[i] = x[i] * (D0[k] / D1[k]);
+    }
+    for (size_t i = tid; i < (size_t)B * m; i += nth) {
+        const size_t b = i / m, mt = shared ? 0 : b, k = mt * m + i % m;
+        const double e = E1[k] / E0[k];
+        l[i] = (T)((double)l[i] * e);
+        u[i] = (T)((double)u[i] * e);
+        z[i] = z[i] * e;
+        lam[i] = lam[i] * ((c1[mt] / c0[mt]) / e);
+    }
+}
+
+// old = the factors in force before the matrix update (copies), handle fields = the new ones
+hipError_t rqp_launch_rescale(const rqp_handle* h, const double* D0, const double* E0, const double* c0, hipStream_t s) {
+    const int sh = h->dims.shared_mats != 0;
+    if (h->esz == 4)
+        k_rescale<float><<<256, 256, 0, s>>>(h->B, h->n, h->m, sh, (float*)h->g, (float*)h->l, (float*)h->u, h->x, h->z, h->lam, D0, E0,
+                                             c0, h->Dsc, h->Esc, h->csc);
+    else
+        k_rescale<double><<<256, 256, 0, s>>>(h->B, h->n, h->m, sh, (double*)h->g, (double*)h->l, (double*)h->u, h->x, h->z, h->lam, D0,
+                                              E0, c0, h->Dsc, h->Esc, h->csc);
+    return hipGetLastError();
+}
+
 hipError_t rqp_launch_ruiz(const rqp_handle* h, hipStream_t s) {
     const size_t lds = ((size_t)h->n + h->m + 256) * sizeof(double);
     if (h->esz == 4)

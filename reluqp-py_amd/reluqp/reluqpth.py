@@ -243,8 +243,9 @@ class ReLU_QP(object):
                     qp.H = self._to_dev(Hx, matlead + (qp.nx, qp.nx), "Hx")
                 if Ax is not None:
                     qp.A = self._to_dev(Ax, matlead + (qp.nc, qp.nx), "Ax")
-                _cabi.check(self._h, lib.rqp_update_mats(self._h, _cabi.ptr(qp.H if Hx is not None else None),
-                                                         _cabi.ptr(qp.A if Ax is not None else None), self._stream()),
+                both = bool(self.settings.scaling)       # with scaling the packed copies are scaled: the ABI wants both raw matrices
+                _cabi.check(self._h, lib.rqp_update_mats(self._h, _cabi.ptr(qp.H if (Hx is not None or both) else None),
+                                                         _cabi.ptr(qp.A if (Ax is not None or both) else None), self._stream()),
                             "rqp_update_mats")
             if g is not None:
                 qp.g = self._to_dev(g, lead + (qp.nx,), "g")

@@ -389,8 +389,27 @@ def test_ruiz_scaling_vs_oracle(prec, tol, kernel, n, n_eq, n_ineq):
     r3 = m.solve()
     ref3 = O.solve_batch(H, g2, A, l, u, form="factored", eps_abs=1e-9, max_iter=50000, scaling=10)
     np.testing.assert_allclose(_np(r3.x) / sx, ref3["x"] / sx, rtol=0, atol=50 * tol)
-    with pytest.raises(_cabi.RqpError):
-        m.update(Hx=H)                                                # new matrices would change D, E: refused, set up again
+    # update(Hx=) with scaling: new D, E, c; vectors and state move to the new scaled space (needs both raw matrices: the
+    # wrapper passes its copies).  Against the oracle doing the same from the same state.
+    H3 = H * 1.5
+    m.update(Hx=H3)
+    r4 = m.solve()
+    refs = []
+    for b in range(B):
+        qp = O.OracleQP(form="factored")
+        qp.setup(H[b], g[b], A[b], l[b], u[b], **kw)
+        qp.solve()
+        qp.update(g=g2[b])
+        qp.solve()
+        qp.update(Hx=H3[b])
+        rb = qp.solve()
+        refs.append((rb.x.copy(), rb.info.iter, rb.info.status))
+    assert list(r4.info.status) == [t[2] for t in refs] == ["solved"] * B
+    it4, it4r = r4.info.iter.cpu().numpy(), np.array([t[1] for t in refs])
+    assert np.all(np.abs(it4 - it4r) <= (0 if prec == torch.float64 else 50))
+    same4 = it4 == it4r
+    x4r = np.stack([t[0] for t in refs])
+    np.testing.assert_allclose((_np(r4.x) / sx)[same4], (x4r / sx)[same4], rtol=0, atol=10 * tol)
 
 
 def test_scaling_helps_badly_scaled_problems():
@@ -575,3 +594,37 @@ def test_large_sizes_streaming_kernel_and_factor_fallbacks(prec, n, n_eq, n_ineq
         same = it == ref["iter"]
         np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0, atol=5e-5 * max(1.0, np.abs(ref["x"]).max()))
     np.testing.assert_allclose(_np(r.x), xs, rtol=0, atol=2e-2 * max(1.0, np.abs(xs).max()))
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "wave", "resident"])
+def test_ruiz_scaling_shared_matrices(kernel):
+    """Shared (H, A): ONE set of Ruiz factors for the whole batch (the cost scaling ignores g for that reason)."""
+    from reluqp import mpc
+    Ad, Bd = mpc.random_plant(6, 2, seed=7)
+    ctl = mpc.LinearMPC(Ad, Bd, np.diag([100.0, 1, 1, 0.01, 1, 1]), 0.1 * np.eye(2), 10, 0.4, 8.0, form="condensed")
+    x0 = 1.5 * np.random.RandomState(7).randn(40, 6)
+    g, l, u = ctl.qp_vectors(x0)
+    kw = dict(eps_abs=1e-4, scaling=10, max_iter=20000)
+    ref = O.solve_batch(ctl.H, g, ctl.A, l, u, form="factored", **kw)
+    m = _solver(ctl.H, g, ctl.A, l, u, precision=torch.float32, kernel=kernel, **kw)
+    r = m.solve()
+    it = r.info.iter.cpu().numpy()
+    assert list(r.info.status) == ref["status"] == ["solved"] * 40
+    assert np.mean(it == ref["iter"]) >= 0.8 and np.all(np.abs(it - ref["iter"]) <= 75)
+    same = it == ref["iter"]
+    np.testing.assert_allclose(_np(r.x)[same], ref["x"][same], rtol=0, atol=2e-4 * max(1.0, np.abs(ref["x"]).max()))
+    np.testing.assert_allclose(_np(r.info.obj_val)[same], ref["obj_val"][same], rtol=1e-3, atol=1e-3)
+
+
+def test_fp16_tile_survives_matrix_update():
+    """update(Hx=) with the fp16 K tile: the packed tile and its power-of-two scales are rebuilt."""
+    H, g, A, l, u, _ = utils.rand_qp_batch(6, 60, 15, 100, seed0=31, feasible=True)
+    m = _solver(H, g, A, l, u, precision=torch.float32, iterate_dtype=torch.float16)
+    assert m.kernel == "resident2"
+    m.solve()
+    H2 = H * 40.0                                                     # K shrinks by ~40: a stale scale would flush it
+    m.update(Hx=H2, g=g * 40.0)
+    r = m.solve()
+    ref = O.solve_batch(H2, g * 40.0, A, l, u, form="factored", eps_abs=1e-9, max_iter=20000)
+    assert all(s == "solved" for s in r.info.status)
+    np.testing.assert_allclose(_np(r.x), ref["x"], rtol=0, atol=2e-2 * max(1.0, np.abs(ref["x"]).max()))
