@@ -151,7 +151,10 @@ int rqp_update(rqp_handle* h, const void* g, const void* l, const void* u, void*
  * 8(f)-4: new H and/or A (same shapes as in rqp_setup; NULL = unchanged).  Re-runs the
  * device setup chain (pack -> A'cA -> K(rho) ladder -> kernel images) on the existing
  * workspace; g, l, u, the equality pattern c, the ADMM state and the rho indices are kept,
- * i.e. the next solve is warm-started exactly like after rqp_update.                     */
+ * i.e. the next solve is warm-started exactly like after rqp_update.  With
+ * settings.scaling > 0 BOTH raw matrices must be given (the packed copies are scaled):
+ * the problem is re-equilibrated and the stored vectors and state move to the new scaled
+ * space (the call then synchronises `stream`).                                           */
 int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream);
 
 /* Parametric form of ReLU_QP.update for linear MPC (the x0 update of the reference's driver,
@@ -179,7 +182,10 @@ int rqp_clear_primal_dual(rqp_handle* h, void* stream);
 /* ReLU_QP.solve + update_results (reluqpth.py:201-249,278-305): the whole ADMM
  * loop of every instance -- iterate (jit_forward :84-89), every check_interval
  * iterations compute_residuals (:307-318), rho-index move (:223-227), termination
- * (:233) -- in ONE kernel launch, one workgroup per instance, no host round trip.
+ * (:233) -- in ONE kernel launch, one workgroup (or wavefront, or MFMA column) per
+ * instance, no host round trip.  Small follow-up launches on the same stream where
+ * they apply: the dispatch-order ranking for the next solve, the straggler pass of a
+ * shared-matrix batch, the certificate pass (check_infeasibility), the un-scaling.
  * Writes x [batch][n], z [batch][m], lam [batch][m] (the state's dual, Q7/Q16) and
  * *info; any of them may be NULL.  Asynchronous on `stream`.                      */
 int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, void* stream);
