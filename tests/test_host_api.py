@@ -136,3 +136,29 @@ def test_generators():
     assert np.array_equal(Hb[0], H) and np.array_equal(gb[0], g) and np.array_equal(xb[0], xs)
     H2, g2, A2, l2, u2, _ = utils.update_qp(H, A, 3, 9, seed=9, compute_sol=False)
     assert np.array_equal(H2, H) and np.array_equal(A2, A) and not np.array_equal(g2, g)
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu():
+    """bench.py's cpu_baseline leg = child processes that never import torch: one worker on a tiny sample, JSON out."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--n", "10", "--n-eq", "3", "--n-ineq", "12", "--batch", "8",
+                          "--cpu-worker", "refine:f32:0:2:5"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["done"] == 4 and d["t_solve"] > 0 and d["iters"] >= 4 * 25      # instances 0, 2, 4, 6 of the batch
+    sys.path.insert(0, REPO)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--workload", "c4"]
+        a = bench.parse()
+        assert (a.n, a.n_eq, a.n_ineq, a.batch, a.scaling) == (32, 8, 56, 8192, "weak")
+        sys.argv = ["bench.py", "--workload", "c4", "--scaling", "strong"]
+        assert bench.parse().batch == 65536
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert (a.batch, a.n, a.n_eq + a.n_ineq, a.precision, a.gpus) == (4096, 100, 300, "f32", 1)
+    finally:
+        sys.argv = old
