@@ -691,28 +691,43 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
     const float* Am = A + (size_t)mat * m * ldn;
     const float* Hm = Ht + (size_t)mat * n * ldn;
+    // every source matrix passes through LDS: coalesced row reads in, the lane-linear gather runs on LDS (the direct
+    // gather from global memory was 4-byte accesses 52 B or a whole row apart: 5 ms per 4096 instances)
+    extern __shared__ __attribute__((aligned(16))) float stage[];        // max(m, n) * ldn floats
     if (blockIdx.x == 0) {
-        float* Ap = Apack + (size_t)mat * AE2 * NT * 2;
-        for (int e = 0; e < AE2 * 2; ++e) {
-            const int pair = e >> 1, h = e & 1;
-            const int r = RB * pl + 2 * (pair / CQ) + h, c = CW * w + CQ * q + pair % CQ;
-            Ap[((size_t)pair * NT + t) * 2 + h] = (r < m && c < n) ? Am[(size_t)r * ldn + c] : 0.f;
+        for (int i = t; i < m * ldn; i += NT) stage[i] = Am[i];
+        __syncthreads();
+        f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
+        for (int pair = 0; pair < AE2; ++pair) {
+            const int r = RB * pl + 2 * (pair / CQ), c = CW * w + CQ * q + pair % CQ;
+            f2 v;
+            v.x = (r < m && c < n) ? stage[r * ldn + c] : 0.f;
+            v.y = (r + 1 < m && c < n) ? stage[(r + 1) * ldn + c] : 0.f;
+            Ap[(size_t)pair * NT + t] = v;
         }
-        float* Hp = Hpack + (size_t)mat * HU * NT * 4;
-        for (int c0 = 0; c0 < CQ; ++c0)                                // unit c0 = (H[HR*pl + 0..3][col(c0)]) : one b128 per column
+        __syncthreads();
+        for (int i = t; i < n * ldn; i += NT) stage[i] = Hm[i];
+        __syncthreads();
+        float4* Hp = (float4*)(Hpack + (size_t)mat * HU * NT * 4);
+        for (int c0 = 0; c0 < CQ; ++c0) {                              // unit c0 = (H[HR*pl + 0..3][col(c0)]) : one b128 per column
+            const int c = CW * w + CQ * q + c0;
+            float hv[HR];
             for (int h = 0; h < HR; ++h) {
-                const int r = HR * pl + h, c = CW * w + CQ * q + c0;
-                // H[r][c] = Ht[c][r]
-                Hp[((size_t)c0 * NT + t) * 4 + h] = (r < n && c < n) ? Hm[(size_t)c * ldn + r] : 0.f;
+                const int r = HR * pl + h;
+                hv[h] = (r < n && c < n) ? stage[c * ldn + r] : 0.f;   // H[r][c] = Ht[c][r]
             }
+            Hp[(size_t)c0 * NT + t] = (float4){hv[0], hv[1], hv[2], hv[3]};
+        }
     } else {
         const int j = blockIdx.x - 1;
         const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
+        for (int i = t; i < n * ldn; i += NT) stage[i] = Kj[i];
+        __syncthreads();
         float inv_scale = 1.f;
         if constexpr (KH) {                                          // block max |K_j| -> power-of-two scale
             __shared__ float smax[NT];
             float mx = 0.f;
-            for (int i = t; i < n * ldn; i += NT) mx = fmaxf(mx, fabsf(Kj[i]));
+            for (int i = t; i < n * ldn; i += NT) mx = fmaxf(mx, fabsf(stage[i]));
             smax[t] = mx;
             __syncthreads();
             for (int off = NT / 2; off >= 1; off >>= 1) {
@@ -726,15 +741,16 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
             if (t == 0) Kscale[(size_t)mat * nrho + j] = sc;
         }
         float* Kp = Kpack + ((size_t)mat * nrho + j) * KE2 * NT * (KH ? 1 : 2);
-        for (int e = 0; e < KE2 * 2; ++e) {
-            const int pair = e >> 1, h = e & 1;
-            const int lr = KR * rr + 2 * (pair / KC) + h;
+        for (int pair = 0; pair < KE2; ++pair) {
+            const int lr = KR * rr + 2 * (pair / KC);
             const int r = CW * w + lr, c = KC * cc + pair % KC;
-            const float v = (lr < CW && r < n && c < n) ? Kj[(size_t)r * ldn + c] : 0.f;
+            f2 v;
+            v.x = (lr < CW && r < n && c < n) ? stage[r * ldn + c] : 0.f;
+            v.y = (lr + 1 < CW && r + 1 < n && c < n) ? stage[(r + 1) * ldn + c] : 0.f;
             if constexpr (KH)
-                ((_Float16*)Kp)[((size_t)pair * NT + t) * 2 + h] = (_Float16)(v * inv_scale);
+                ((h2*)Kp)[(size_t)pair * NT + t] = (h2){(_Float16)(v.x * inv_scale), (_Float16)(v.y * inv_scale)};
             else
-                Kp[((size_t)pair * NT + t) * 2 + h] = v;
+                ((f2*)Kp)[(size_t)pair * NT + t] = v;
         }
     }
 }
@@ -774,11 +790,12 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
 template <class C>
 static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
     dim3 grid(1 + h->nrho, h->nmat);
+    const size_t stage = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
     if (h->dims.tile_dtype == RQP_TILE_F16)
-        k_pack_res2<C, true><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+        k_pack_res2<C, true><<<grid, C::NT, stage, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
                                                     (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
     else
-        k_pack_res2<C, false><<<grid, C::NT, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
+        k_pack_res2<C, false><<<grid, C::NT, stage, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
                                                      (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
     return hipGetLastError();
 }
@@ -794,6 +811,13 @@ hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
 template <class C>
 static hipError_t prepare_t(const rqp_handle* h) {
     const size_t lds = C::lds_bytes();
+    {   // pack kernel: its LDS stage holds a whole source matrix (up to m x ldn floats = 128 KB on the big tile)
+        const size_t stage = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
+        hipError_t pe = (h->dims.tile_dtype == RQP_TILE_F16)
+                            ? hipFuncSetAttribute((const void*)k_pack_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage)
+                            : hipFuncSetAttribute((const void*)k_pack_res2<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage);
+        if (pe != hipSuccess) return pe;
+    }
     if (h->dims.tile_dtype == RQP_TILE_F16)
         return hipFuncSetAttribute((const void*)k_admm_res2<C, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
