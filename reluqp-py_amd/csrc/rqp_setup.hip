@@ -424,6 +424,94 @@ __global__ void __launch_bounds__(256, 3) k_factor_reg(SetupArgs a) {
         }
 }
 
+
+// Second register layout of the same symmetric sweep, for the LDS return path: in k_factor_reg every lane reads the R
+// row values of its slice (wave-uniform addresses, but a broadcast ds_read still returns 64 x 16 B), 26 KB of LDS
+// return per wave and step against 52 FMAs per lane -- the kernel ran at the LDS return bandwidth (832 cycles per
+// workgroup-step, 208 of FMA issue).  Here thread (ty, tx) of a 16 x 16 grid owns the RT x RT elements
+// (ty + 16 i, tx + 16 j): it needs RT row values for its rows and RT for its columns -- 2 RT reads for RT^2 FMAs
+// (n <= 16 RT; RT = 7: 14 reads for 49 FMAs) -- and the column-k / row-k fix-ups touch RT elements instead of R.
+template <typename T, int RT>
+__global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
+    constexpr int NMAX = 16 * RT;
+    __shared__ __attribute__((aligned(16))) double rowbuf[2][NMAX];
+    __shared__ __attribute__((aligned(16))) double tb[RT][16][17];       // one symmetrisation pass: RT blocks, closed under transposition
+    const int n = a.n;
+    const int mat = blockIdx.x / a.nrho, jrho = blockIdx.x % a.nrho;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
+    const double* G = a.G + (size_t)mat * n * n;
+    const double rho = a.rhos[jrho];
+    double mreg[RT][RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            const int r = ty + 16 * i, c = tx + 16 * j;
+            mreg[i][j] = 0.0;
+            if (r < n && c < n) mreg[i][j] = (double)Ht[(size_t)r * a.ldn + c] + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
+        }
+    // (every thread divides by the pivot after the barrier: letting only the 16 owners of row k divide -- they would post
+    //  row / d as well -- puts a cross-lane fetch of d and the division in front of the barrier: 8.9 ms instead of 7.6)
+    auto step = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k < n) {                                                      // uniform
+            constexpr int kb = k / 16, ko = k % 16;                       // row / column block and offset of the pivot
+            double* rb = rowbuf[k & 1];
+            if (ty == ko) {                                               // owners of row k: RT values each
+#pragma unroll
+                for (int j = 0; j < RT; ++j) rb[tx + 16 * j] = mreg[kb][j];
+            }
+            __syncthreads();
+            const double p = 1.0 / rb[k];
+            double rr[RT], tc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) rr[i] = rb[ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < RT; ++j) tc[j] = rb[tx + 16 * j];
+#pragma unroll
+            for (int j = 0; j < RT; ++j) tc[j] = -tc[j] * p;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) mreg[i][j] = fma(rr[i], tc[j], mreg[i][j]);
+            if (tx == ko) {                                               // column k: row[r] / d
+#pragma unroll
+                for (int i = 0; i < RT; ++i) mreg[i][kb] = rr[i] * p;
+            }
+            if (ty == ko) {                                               // row k: row[c] / d ; pivot: -1 / d
+#pragma unroll
+                for (int j = 0; j < RT; ++j) mreg[kb][j] = -tc[j];
+                if (tx == ko) mreg[kb][kb] = -p;
+            }
+        }
+    };
+    rqp_static_for(std::make_integer_sequence<int, NMAX>{}, step);
+    // K_j = -(M + M')/2: block (i, j) of thread (ty, tx) meets block (j, i) of thread (tx, ty) through LDS; pass d moves the
+    // RT blocks with (i + j) mod RT == d (a set closed under transposition), slot i = block (i, (d - i) mod RT)
+    T* K = (T*)a.K + ((size_t)mat * a.nrho + jrho) * n * a.ldn;
+#pragma unroll
+    for (int d = 0; d < RT; ++d) {                                        // pass d: blocks with (i + j) % RT == d (closed under transposition)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) tb[i][ty][tx] = mreg[i][(d - i + RT) % RT];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int j = (d - i + RT) % RT;
+            const int r = ty + 16 * i, c = tx + 16 * j;
+            const double mt = tb[j][tx][ty];                              // M[c][r]: thread (tx, ty), block (j, i) = slot j of this pass
+            if (r < n && c < a.ldn) K[(size_t)r * a.ldn + c] = (c < n) ? (T)(-0.5 * (mreg[i][j] + mt)) : T(0);
+        }
+    }
+}
+
+template <typename T, int RT>
+static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    k_factor_reg2<T, RT><<<h->nmat * h->nrho, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
 template <typename T, int CB, int R>
 static hipError_t launch_factor_reg(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     k_factor_reg<T, CB, R><<<h->nmat * h->nrho, 256, 0, s>>>(a);
@@ -441,10 +529,10 @@ static hipError_t launch_factor_fast(rqp_handle* h, const SetupArgs& a, hipStrea
 
 hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     const int n = h->n;
-    if (n <= 32) return h->esz == 4 ? launch_factor_reg<float, 5, 4>(h, a, s) : launch_factor_reg<double, 5, 4>(h, a, s);
-    if (n <= 64) return h->esz == 4 ? launch_factor_reg<float, 6, 16>(h, a, s) : launch_factor_reg<double, 6, 16>(h, a, s);
-    if (n <= 104 && h->ldn <= 128)
-        return h->esz == 4 ? launch_factor_reg<float, 7, 52>(h, a, s) : launch_factor_reg<double, 7, 52>(h, a, s);
+    if (n <= 32) return h->esz == 4 ? launch_factor_reg2<float, 2>(h, a, s) : launch_factor_reg2<double, 2>(h, a, s);
+    if (n <= 64) return h->esz == 4 ? launch_factor_reg2<float, 4>(h, a, s) : launch_factor_reg2<double, 4>(h, a, s);
+    if (n <= 112 && h->ldn <= 112)
+        return h->esz == 4 ? launch_factor_reg2<float, 7>(h, a, s) : launch_factor_reg2<double, 7>(h, a, s);
     if (n <= 64) return h->esz == 4 ? launch_factor_fast<float, 64>(h, a, s) : launch_factor_fast<double, 64>(h, a, s);
     if (n <= 128 && h->ldn <= 128)
         return h->esz == 4 ? launch_factor_fast<float, 128>(h, a, s) : launch_factor_fast<double, 128>(h, a, s);
