@@ -342,95 +342,19 @@ __global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
 }
 
 
-// Register-resident factorisation for n <= 104 (the sizes of every resident ADMM tile): M_j never leaves the VGPRs.
-// Thread (c = tid % NCOL, rs = tid / NCOL) owns column c of the row slice [rs R, rs R + R): R doubles in registers.
+// Register-resident factorisation for n <= 112 (the sizes of every resident ADMM tile): M_j never leaves the VGPRs.
 // In-place SYMMETRIC SWEEP (M -> -M^-1, SPD, no pivoting): at step k, with row = old row k (= old column k), d = row[k],
 //     M[r][c] -= row[r] row[c] / d   (r, c != k);   M[r][k] = M[k][r] = row[r] / d;   M[k][k] = -1 / d
-// so only ROW k has to be shared: its owners write one value each to LDS (double-buffered: ONE barrier per step), every
-// thread reads row[c] once and row[r] of its R rows with wave-uniform (broadcast) addresses, then R FMAs from registers.
-// The LDS Gauss-Jordan above moves 24 bytes of LDS per FMA; here it is 8 bytes per R FMAs and lane.  The step loop is
-// fully unrolled (the pivot row's register index must be a compile-time constant).  2.5 KB of LDS + a 13-row transpose
-// buffer for the final symmetrisation; 3 workgroups per CU.
-template <typename T, int CB, int R>
-__global__ void __launch_bounds__(256, 3) k_factor_reg(SetupArgs a) {
-    constexpr int NCOL = 1 << CB, RS = 256 / NCOL, NMAX = RS * R, CH = (R % 4 == 0) ? R / 4 : R, NCH = R / CH;
-    constexpr int NB = NCOL > NMAX ? NCOL : NMAX;
-    static_assert(RS * NCOL == 256 && NMAX <= NCOL && R % CH == 0, "slice layout");
-    __shared__ __attribute__((aligned(16))) double rowbuf[2][NB];
-    __shared__ __attribute__((aligned(16))) double tb[CH][NMAX];          // transposed chunk for the symmetrisation
-    const int n = a.n;
-    const int mat = blockIdx.x / a.nrho, j = blockIdx.x % a.nrho;
-    const int tid = threadIdx.x, c = tid & (NCOL - 1), rs = tid >> CB;
-    const bool cin = c < n;
-    const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
-    const double* G = a.G + (size_t)mat * n * n;
-    const double rho = a.rhos[j];
-    double mreg[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int r = rs * R + i;
-        mreg[i] = 0.0;
-        if (cin && r < n) mreg[i] = (double)Ht[(size_t)r * a.ldn + c] + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];   // Ht = sym(H)
-    }
-    // (the steps are instantiated one by one -- a fold over an integer sequence: `#pragma unroll` gives up on 104 steps of this
-    //  size, and a rolled loop would index the pivot row's register dynamically, i.e. put M in scratch memory)
-    auto step = [&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        if (k < n) {                                                      // uniform: steps past n are skipped
-            constexpr int ks = k / R, ki = k % R;
-            double* rb = rowbuf[k & 1];
-            if (rs == ks) rb[c] = mreg[ki];                               // old row k
-            __syncthreads();
-            const double rc = rb[c];
-            const double p = 1.0 / rb[k];
-            const double t = -rc * p;
-            const double* rrow = rb + rs * R;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) {                               // chunks keep the live row values few (registers)
-                double rr[CH];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) rr[i] = rrow[q * CH + i];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) mreg[q * CH + i] = fma(rr[i], t, mreg[q * CH + i]);
-                if (c == k) {                                             // column k (one lane per slice): row[r] / d
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) mreg[q * CH + i] = rr[i] * p;
-                }
-            }
-            if (rs == ks) mreg[ki] = (c == k) ? -p : rc * p;              // row k: row[c] / d, pivot -1/d
-        }
-    };
-    rqp_static_for(std::make_integer_sequence<int, NMAX>{}, step);
-    // K_j = -M, symmetrised with the transposed element (held by another thread) through LDS, CH rows at a time
-    T* K = (T*)a.K + ((size_t)mat * a.nrho + j) * n * a.ldn;
-#pragma unroll
-    for (int s = 0; s < RS; ++s)
-#pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-            const int g0 = s * R + q * CH;                                // rows (and columns) g0 .. g0 + CH - 1
-            __syncthreads();
-            if (c >= g0 && c < g0 + CH) {                                 // owners of columns g0..: M[row][c] -> tb[c - g0][row]
-#pragma unroll
-                for (int i = 0; i < R; ++i) tb[c - g0][rs * R + i] = mreg[i];
-            }
-            __syncthreads();
-            if (rs == s && c < a.ldn) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int r = g0 + i;
-                    if (r < n) K[(size_t)r * a.ldn + c] = cin ? (T)(-0.5 * (mreg[q * CH + i] + tb[i][c])) : T(0);
-                }
-            }
-        }
-}
-
-
-// Second register layout of the same symmetric sweep, for the LDS return path: in k_factor_reg every lane reads the R
-// row values of its slice (wave-uniform addresses, but a broadcast ds_read still returns 64 x 16 B), 26 KB of LDS
-// return per wave and step against 52 FMAs per lane -- the kernel ran at the LDS return bandwidth (832 cycles per
-// workgroup-step, 208 of FMA issue).  Here thread (ty, tx) of a 16 x 16 grid owns the RT x RT elements
-// (ty + 16 i, tx + 16 j): it needs RT row values for its rows and RT for its columns -- 2 RT reads for RT^2 FMAs
-// (n <= 16 RT; RT = 7: 14 reads for 49 FMAs) -- and the column-k / row-k fix-ups touch RT elements instead of R.
+// so only ROW k has to be shared: its owners write it to LDS (double-buffered: ONE barrier per step).  The LDS Gauss-Jordan
+// (k_factor_fast below, round 1) moves 24 bytes of LDS per FMA.  The step loop is fully instantiated (a fold over an
+// integer sequence: the pivot row's register index must be a compile-time constant, and `#pragma unroll` gives up on 100+
+// steps of this size -- a rolled loop would index registers dynamically, i.e. put M in scratch memory).
+// Thread layout: a first version gave thread (column, row slice) a column strip of R = 52 rows; every lane then read the R
+// row values of its slice per step (wave-uniform addresses, but a broadcast ds_read still returns 64 x 16 B): 26 KB of LDS
+// return per wave and step against 52 FMAs per lane -- it ran at the LDS return bandwidth (12.4 ms for the 73 728 matrices
+// of the headline batch).  Thread (ty, tx) of a 16 x 16 grid now owns the RT x RT elements (ty + 16 i, tx + 16 j): RT row
+// values for its rows and RT for its columns -- 2 RT reads for RT^2 FMAs (n <= 16 RT; RT = 7: 14 reads for 49 FMAs) --
+// and the column-k / row-k fix-ups touch RT elements instead of R: 7.6 ms.
 template <typename T, int RT>
 __global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
     constexpr int NMAX = 16 * RT;
@@ -509,12 +433,6 @@ __global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
 template <typename T, int RT>
 static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     k_factor_reg2<T, RT><<<h->nmat * h->nrho, 256, 0, s>>>(a);
-    return hipGetLastError();
-}
-
-template <typename T, int CB, int R>
-static hipError_t launch_factor_reg(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
-    k_factor_reg<T, CB, R><<<h->nmat * h->nrho, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 
