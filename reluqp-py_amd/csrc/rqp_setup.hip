@@ -221,7 +221,68 @@ __global__ void __launch_bounds__(256) k_gram(SetupArgs a) {
         }
 }
 
+// n <= 16 RT: one workgroup per matrix in the 16 x 16 x (RT x RT) register layout of k_factor_reg2: 2 RT LDS reads for
+// RT^2 FMAs (the 64 x 64-tile kernel above spends 8 reads on 16 FMAs and pads n = 100 to two tiles per dimension).
+template <typename T, int RT>
+__global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
+    constexpr int NMAX = 16 * RT, KB = 16;
+    __shared__ __attribute__((aligned(16))) double sR[KB][NMAX];         // c_k A[k][:]
+    __shared__ __attribute__((aligned(16))) double sC[KB][NMAX];         // A[k][:]
+    const int mat = blockIdx.x, n = a.n, m = a.m;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const T* A = (const T*)a.A + (size_t)mat * m * a.ldn;
+    const T* cv = (const T*)a.c + (size_t)mat * m;                       // shared mats: instance 0's pattern (mat = 0)
+    double acc[RT][RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < m; k0 += KB) {
+        for (int e = tid; e < KB * NMAX; e += 256) {
+            const int kk = e / NMAX, col = e % NMAX, k = k0 + kk;
+            const double v = (k < m && col < n) ? (double)A[(size_t)k * a.ldn + col] : 0.0;
+            sC[kk][col] = v;
+            sR[kk][col] = (k < m) ? v * (double)cv[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < KB; ++kk) {
+            double rr[RT], cc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) rr[i] = sR[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < RT; ++j) cc[j] = sC[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) acc[i][j] = fma(rr[i], cc[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    double* G = a.G + (size_t)mat * n * n;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            const int r = ty + 16 * i, c = tx + 16 * j;
+            if (r < n && c < n) G[(size_t)r * n + c] = acc[i][j];
+        }
+}
+
 hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    if (h->n <= 32) {
+        if (h->esz == 4) k_gram2<float, 2><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 2><<<h->nmat, 256, 0, s>>>(a);
+        return hipGetLastError();
+    }
+    if (h->n <= 64) {
+        if (h->esz == 4) k_gram2<float, 4><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 4><<<h->nmat, 256, 0, s>>>(a);
+        return hipGetLastError();
+    }
+    if (h->n <= 112) {
+        if (h->esz == 4) k_gram2<float, 7><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 7><<<h->nmat, 256, 0, s>>>(a);
+        return hipGetLastError();
+    }
+
     int t = (h->n + GR_T - 1) / GR_T;
     dim3 grid(t, t, h->nmat);
     if (h->esz == 4)
