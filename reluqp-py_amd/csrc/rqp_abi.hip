@@ -347,7 +347,6 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->cont_iter_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->cont_rho_d, (size_t)h->B * sizeof(double)));
         h->handoff_cols = 6;    // measured on the config-3 batch: 4.7 M QP/s without, 5.0 M at 2-4, 6.2 M at 6-10, 5.5 M at 12 (tools/)
-        if (const char* e = getenv("RQP_HANDOFF_COLS")) h->handoff_cols = atoi(e);      // tuning aid (read at setup only)
     }
     SetupArgs a = make_setup_args(h, H, g, A, l, u);
     HIP_TRY(h, rqp_launch_pack_vecs(h, a, s));

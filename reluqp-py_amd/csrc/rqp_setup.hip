@@ -448,7 +448,12 @@ __global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
                 for (int j = 0; j < RT; ++j) rb[tx + 16 * j] = mreg[kb][j];
             }
             __syncthreads();
-            const double p = 1.0 / rb[k];
+            // 1 / d: hardware reciprocal + two Newton steps (5 instructions; the IEEE division sequence is ~15, and every
+            // thread runs it every step).  d > 0 is a Schur-complement pivot of an SPD matrix: no special cases to fix up.
+            const double dk = rb[k];
+            double p = __builtin_amdgcn_rcp(dk);
+            p = fma(p, fma(-dk, p, 1.0), p);
+            p = fma(p, fma(-dk, p, 1.0), p);
             double rr[RT], tc[RT];
 #pragma unroll
             for (int i = 0; i < RT; ++i) rr[i] = rb[ty + 16 * i];
