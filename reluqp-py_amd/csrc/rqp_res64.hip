@@ -15,7 +15,9 @@
 //   A dx  : needs only the wave's own 13 dx values; the 8 per-wave partial row sums meet in LDS and are added in fixed
 //           order by the row's owner thread (row i <-> thread i), which keeps z, lam, A x of its row in registers.
 // 3 barriers per iteration.  182 float64 FMAs per lane and iteration: float64 VALU-bound.
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "rqp_common.h"
 
@@ -26,7 +28,7 @@ constexpr int R64_RS = 66;                         // stride (doubles) of a colu
 constexpr size_t r64_lds_doubles() {
     return (size_t)R64_N * R64_N                   // Hs [col][row]
            + (size_t)R64_NW * R64_CW * R64_RS      // reduce slabs; the A dx partials part[8][320] alias their start
-           + 3 * R64_M + 4 * R64_N + 64 + 16;      // nu, l, u | d | dx | x | H x | reductions | check scalars
+           + 5 * R64_M + 4 * R64_N + 64 + 16;      // nu, l, u, rho, 1/rho | d | g | x | H x | reductions | check scalars
 }
 
 // v + (v of lane ^ 1) and v + (v of lane ^ 2): quad permutes on the two 32-bit halves (DPP, no LDS round trip --
@@ -43,6 +45,57 @@ __device__ __forceinline__ double quad_sum(double v) {     // sum over the 4 lan
     return dpp_add64<0x4E>(v);                             // quad_perm [2,3,0,1]
 }
 
+// wave-wide reductions of the checks, in registers (DPP inside a row of 16 lanes, v_permlane16/32_swap across rows; the
+// swaps as inline asm with the 2 wait states a VALU-written operand needs -- see rqp_resident2.hip)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_max64(double v) {                  // max(v, v of the DPP partner); NaN-free inputs
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)u), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(u >> 32));
+    return fmax(v, __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void swap16(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ double rows_max64(double v) {                 // max over the 4 rows of 16 lanes, same lane of each row
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int alo = (int)(unsigned)u, blo = alo, ahi = (int)(unsigned)(u >> 32), bhi = ahi;
+    swap16(alo, blo);
+    swap16(ahi, bhi);
+    double x = fmax(__builtin_bit_cast(double, ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo),
+                    __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo));
+    const unsigned long long w = __builtin_bit_cast(unsigned long long, x);
+    alo = (int)(unsigned)w; blo = alo; ahi = (int)(unsigned)(w >> 32); bhi = ahi;
+    swap32(alo, blo);
+    swap32(ahi, bhi);
+    return fmax(__builtin_bit_cast(double, ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo),
+                __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo));
+}
+__device__ __forceinline__ int rows_or(int v) {
+    int a = v, b = v;
+    swap16(a, b);
+    v = a | b;
+    a = v; b = v;
+    swap32(a, b);
+    return a | b;
+}
+__device__ __forceinline__ double wave_max64(double v) {                 // every lane gets the max over the 64 lanes
+    v = dpp_max64<0xB1>(v);                                            // quad_perm [1,0,3,2]
+    v = dpp_max64<0x4E>(v);                                            // quad_perm [2,3,0,1]
+    v = dpp_max64<0x141>(v);                                           // row_half_mirror
+    v = dpp_max64<0x140>(v);                                           // row_mirror
+    return rows_max64(v);
+}
+__device__ __forceinline__ int wave_or_i(int v) {
+    v |= dpp_i<0xB1>(v);
+    v |= dpp_i<0x4E>(v);
+    v |= dpp_i<0x141>(v);
+    v |= dpp_i<0x140>(v);
+    return rows_or(v);
+}
+
 template <typename U>
 __device__ __forceinline__ U tmx(U a, U b) {       // torch.max / norm(inf): NaN propagates
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
@@ -50,7 +103,10 @@ __device__ __forceinline__ U tmx(U a, U b) {       // torch.max / norm(inf): NaN
 
 }   // namespace
 
-__global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
+// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the cycles each wave spends in
+// every segment of the iteration into `dbg` (never read by the kernel; never timed as the product).
+template <bool DIAG>
+__global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned long long* dbg) {
     constexpr int NT = R64_NT, NW = R64_NW, CW = R64_CW, RL = R64_RL, N = R64_N, M = R64_M, KC = R64_KC, RS = R64_RS;
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     double* Hs = sm64;                             // [N][N]: Hs[col * N + row]
@@ -59,9 +115,11 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
     double* nuL = slab + NW * CW * RS;             // [M]
     double* loL = nuL + M;                         // [M] l  (row bounds wait in LDS: the register file is full of A and K)
     double* hiL = loL + M;                         // [M] u
-    double* dL = hiL + M;                          // [N]
-    double* dxL = dL + N;                          // [N]
-    double* xL = dxL + N;                          // [N]
+    double* rvL = hiL + M;                         // [M] rho_i
+    double* invL = rvL + M;                        // [M] 1 / rho_i
+    double* dL = invL + M;                         // [N]
+    double* gL = dL + N;                           // [N]
+    double* xL = gL + N;                           // [N]
     double* hxL = xL + N;                          // [N] H x of the last check (objective at the exit)
     double* red = hxL + N;                         // [64]
     double* stat = red + 64;                       // [16] scalars of the last check: pri, dua, rho estimate, scales (they are
@@ -103,7 +161,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
 
     // ---- state.  Row i <-> thread i (i < M): z, lam, A x, bounds, rho in registers.  Column 13 w + rr <-> lane cc == 0.
     const bool rown = tid < M, rin = tid < m;
-    double zt = 0.0, z = 0.0, lam = 0.0, rv = 1.0, inv = 1.0;
+    double zt = 0.0, z = 0.0, lam = 0.0;
     if (rin) {
         z = a.z[(size_t)b * m + tid];
         lam = a.lam[(size_t)b * m + tid];
@@ -112,36 +170,43 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
         loL[tid] = rin ? ((const double*)a.l)[(size_t)b * m + tid] : 0.0;
         hiL[tid] = rin ? ((const double*)a.u)[(size_t)b * m + tid] : 0.0;
     }
-    auto set_rho = [&](int j) {
-        rv = a.rhos[j] * (rin ? ((const double*)a.c)[(size_t)b * m + tid] : 1.0);
-        inv = 1.0 / rv;
+    auto set_rho = [&](int j) {                    // (row i is written and read by thread i only: no barrier)
+        if (!rown) return;
+        const double rv = a.rhos[j] * (rin ? ((const double*)a.c)[(size_t)b * m + tid] : 1.0);
+        rvL[tid] = rv;
+        invL[tid] = 1.0 / rv;
     };
     set_rho(ri);
     const int xcol = CW * wave + rr;
     const bool xown = cc == 0 && rr < CW;
     const bool xin = xown && xcol < n;
     double x = xin ? a.x[(size_t)b * n + xcol] : 0.0;
-    const double gx = xin ? ((const double*)a.g)[(size_t)b * n + xcol] : 0.0;
     if (xown) {
         xL[xcol] = x;
-        dxL[xcol] = x;                             // start pass: A x of the incoming state through the A dx product
+        gL[xcol] = xin ? ((const double*)a.g)[(size_t)b * n + xcol] : 0.0;
     }
     if (rown) nuL[tid] = 0.0;
     __syncthreads();
 
     // ---- products ------------------------------------------------------------------------------------------------
-    // wave partial of A v over the wave's 13 columns -> part[wave][row]
-    auto prod_A = [&](const double* v) {
-        double vc[CW];
+    // wave partial of A v over the wave's 13 columns -> part[wave][row].  v[13 w + c] is held by lane 4 c of this very
+    // wave (the column owners), so it is broadcast through v_readlane into a scalar register pair -- no LDS hop on the
+    // critical path, no 13 broadcast reads (an LDS broadcast still returns 64 x 8 bytes), no 26 live VGPRs
+    auto prod_A = [&](const double vown) {
+        const unsigned long long vb = __builtin_bit_cast(unsigned long long, vown);
+        const int vlo = (int)(unsigned)vb, vhi = (int)(unsigned)(vb >> 32);
+        double s[RL];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) vc[c] = v[CW * wave + c];
+        for (int r = 0; r < RL; ++r) s[r] = 0.0;
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            double s = 0.0;
+        for (int c = 0; c < CW; ++c) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(vlo, 4 * c), hi = (unsigned)__builtin_amdgcn_readlane(vhi, 4 * c);
+            const double vc = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 #pragma unroll
-            for (int c = 0; c < CW; ++c) s = fma(ar[r][c], vc[c], s);
-            part[wave * M + RL * lane + r] = s;
+            for (int r = 0; r < RL; ++r) s[r] = fma(ar[r][c], vc, s[r]);
         }
+#pragma unroll
+        for (int r = 0; r < RL; ++r) part[wave * M + RL * lane + r] = s[r];
     };
     // [USE_A: A' w] + [USE_H: H xL] for the wave's own columns; lanes (c = lane >> 2 < 13, cc == 0) return the column sum
     auto prod_At = [&](bool use_a, bool use_h, const double* w) -> double {
@@ -211,12 +276,13 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
         }
         if (do_a) {
             const double lo = loL[tid], hi = hiL[tid];
-            const double v = zt + lam * inv;
+            const double v = zt + lam * invL[tid];
             z = v;                                                    // torch.clamp: NaN stays NaN
             if (v < lo) z = lo;
             if (v > hi) z = hi;
         }
         if (do_b) {
+            const double rv = rvL[tid];
             const double pr = zt - z;
             const double lh = lam + rv * pr;
             lam = lh;
@@ -234,7 +300,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
     const int kmax = (a.mode == 2) ? 0 : a.max_iter;
 
     // A x of the incoming state
-    prod_A(dxL);
+    prod_A(x);
     __syncthreads();
     row_pass(true, false, kmax > 0);
 
@@ -253,26 +319,44 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
         __syncthreads();                                              // (slab reuse)
         const double t2 = prod_At(false, true, nuL);                  // H x
         if (xown) {
+            const double gx = gL[xcol];
             hxL[xcol] = t2;
             v[3] = fabs(t2 + t3 + gx);
             v[4] = fabs(t2);
             v[5] = fabs(t3);
             v[6] = fabs(gx);
         }
+        // 7 maxima over the workgroup, NaN-propagating like torch.max / norm(inf): NaN flags travel as a bit mask, the values
+        // through v_max_f64 (which skips NaN).  Wave level in registers; the 8 waves meet in LDS and wave 0 finishes:
+        // lane (w, e) = (lane >> 3, lane & 7) takes wave w's value e (e == 7: its NaN mask), lanes 8 apart are combined.
+        int nanm = 0;
 #pragma unroll
-        for (int e = 0; e < 7; ++e)
+        for (int e = 0; e < 7; ++e) nanm |= (v[e] != v[e]) ? (1 << e) : 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v[e] = tmx(v[e], __shfl_xor(v[e], off, 64));
-        __syncthreads();
-        if (lane == 0)
+        for (int e = 0; e < 7; ++e) v[e] = wave_max64(v[e]);
+        nanm = wave_or_i(nanm);
+        if (lane == 0) {                                              // (red: the previous check's readers passed a barrier since)
 #pragma unroll
             for (int e = 0; e < 7; ++e) red[wave * 8 + e] = v[e];
+            ((int*)(red + wave * 8 + 7))[0] = nanm;
+        }
         __syncthreads();
+        if (wave == 0) {
+            double r = red[lane];                                     // (lane & 7) == 7: NaN mask in the low dword
+            int mk = ((const int*)(red + lane))[0];
+            if ((lane & 7) == 7) r = 0.0;
+            r = dpp_max64<0x128>(r);                                  // row_ror:8  -> lanes 8 apart inside a row
+            mk |= dpp_i<0x128>(mk);
+            r = rows_max64(r);
+            mk = rows_or(mk);
+            const int allnan = __builtin_amdgcn_readlane(mk, 7);
 #pragma unroll
-        for (int e = 0; e < 7; ++e) {
-            double r = red[e];
-            for (int w = 1; w < NW; ++w) r = tmx(r, red[w * 8 + e]);
-            v[e] = r;
+            for (int e = 0; e < 7; ++e) {
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, r);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, e);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), e);
+                v[e] = ((allnan >> e) & 1) ? __builtin_nan("") : __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            }
         }
         if (tid == 0) {
             const double sp = tmx(v[1], v[2]), sd = tmx(tmx(v[4], v[5]), v[6]);
@@ -290,31 +374,46 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
         __syncthreads();
     };
 
+    unsigned long long t_last = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int seg) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0) t_acc[seg] += t - t_last;
+            t_last = t;
+        }
+    };
+    stamp(-1);
     int to_chk = a.check_interval;
     for (int k = 1; k <= kmax; ++k) {
         __syncthreads();                                              // B3: nu (and x) visible
-        const double d = prod_At(true, true, nuL) + gx;               // d = H x + g + A' nu   (own columns)
-        if (xown) dL[xcol] = d;
+        stamp(0);
+        const double d = prod_At(true, true, nuL);                    // d = H x + g + A' nu   (own columns)
+        if (xown) dL[xcol] = d + gL[xcol];
+        stamp(1);
         __syncthreads();                                              // B1: d visible (the slabs are free: part may be written)
+        stamp(2);
         {
-            const double kd = prod_K(dL);
+            const double dx = -prod_K(dL);                            // (lanes cc == 0; rows >= 13 of the group are zero rows of K)
             if (xown) {
-                const double dx = -kd;
                 x += dx;
-                dxL[xcol] = dx;
                 xL[xcol] = x;
             }
+            stamp(3);
+            prod_A(dx);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // dx of this wave's columns: same-wave LDS hop
-        __builtin_amdgcn_wave_barrier();
-        prod_A(dxL);
+        stamp(4);
         __syncthreads();                                              // B2: partials and x visible
+        stamp(5);
         iters = k;
         const bool on_grid = (--to_chk == 0);
         if (on_grid) to_chk = a.check_interval;
         const bool check = (a.mode == 0) && on_grid;                  // reluqpth.py:218 (Q3 fixed)
         if (!check) {
             row_pass(false, true, k < kmax);
+            stamp(6);
         } else {
             row_pass(false, true, false);
             const int ri_before = ri;
@@ -339,7 +438,12 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
                 set_rho(ri);
             }
             if (k < kmax) row_pass(false, false, true);
+            stamp(7);
         }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0)
+            for (int e = 0; e < 9; ++e) dbg[((size_t)b * NW + wave) * 9 + e] = (e == 8) ? (unsigned long long)iters : t_acc[e];
     }
 
     __syncthreads();
@@ -355,7 +459,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
     const double pri = stat[0], dua = stat[1], rho_est = stat[2];
 
     // objective 1/2 x'Hx + g'x (compute_J :320-322): hxL = H x of the last check
-    double jp = xown ? x * (0.5 * hxL[xcol] + gx) : 0.0;
+    double jp = xown ? x * (0.5 * hxL[xcol] + gL[xcol]) : 0.0;
     for (int off = 32; off >= 1; off >>= 1) jp += __shfl_xor(jp, off, 64);
     if (lane == 0) red[wave] = jp;
     __syncthreads();
@@ -398,12 +502,38 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a) {
 bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N && h->m <= R64_M; }
 
 hipError_t rqp_prepare_res64(const rqp_handle* h) {
-    (void)h;
-    return hipFuncSetAttribute((const void*)k_admm_res64, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(r64_lds_doubles() * sizeof(double)));
+    const int lds = (int)(r64_lds_doubles() * sizeof(double));
+    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess && (h->debug & 2))
+        e = hipFuncSetAttribute((const void*)k_admm_res64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
 }
 
 hipError_t rqp_launch_solve_res64(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    k_admm_res64<<<h->B, R64_NT, r64_lds_doubles() * sizeof(double), s>>>(a);
+    const size_t lds = r64_lds_doubles() * sizeof(double);
+    if (h->debug & 2) {          // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+        unsigned long long* dbg = nullptr;
+        const size_t cnt = (size_t)h->B * R64_NW * 9;
+        if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
+        k_admm_res64<true><<<h->B, R64_NT, lds, s>>>(a, dbg);
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> hbuf(cnt);
+        (void)hipMemcpy(hbuf.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        static const char* names[8] = {"B3 wait", "A'nu+Hx", "B1 wait", "Kd+x", "A dx", "B2 wait", "rows", "check"};
+        for (int w = 0; w < R64_NW; ++w) {
+            double tot[8] = {0}, its = 0;
+            for (int b = 0; b < h->B; ++b) {
+                for (int e = 0; e < 8; ++e) tot[e] += (double)hbuf[((size_t)b * R64_NW + w) * 9 + e];
+                its += (double)hbuf[((size_t)b * R64_NW + w) * 9 + 8];
+            }
+            fprintf(stderr, "[rqp diag64] wave %d cycles/iteration:", w);
+            double sum = 0;
+            for (int e = 0; e < 8; ++e) { fprintf(stderr, " %s=%.0f", names[e], tot[e] / its); sum += tot[e] / its; }
+            fprintf(stderr, " | total=%.0f\n", sum);
+        }
+        return hipGetLastError();
+    }
+    k_admm_res64<false><<<h->B, R64_NT, lds, s>>>(a, nullptr);
     return hipGetLastError();
 }
