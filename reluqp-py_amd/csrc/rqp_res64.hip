@@ -28,7 +28,7 @@ constexpr int R64_RS = 66;                         // stride (doubles) of a colu
 constexpr size_t r64_lds_doubles() {
     return (size_t)R64_N * R64_N                   // Hs [col][row]
            + (size_t)R64_NW * R64_CW * R64_RS      // reduce slabs; the A dx partials part[8][320] alias their start
-           + 5 * R64_M + 4 * R64_N + 64 + 16;      // nu, l, u, rho, 1/rho | d | g | x | H x | reductions | check scalars
+           + 5 * R64_M + 4 * R64_N + 64 + 16 + 32; // nu, l, u, rho, 1/rho | d | g | x | H x | reductions | check scalars | rho ladder
 }
 
 // v + (v of lane ^ 1) and v + (v of lane ^ 2): quad permutes on the two 32-bit halves (DPP, no LDS round trip --
@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     double* red = hxL + N;                         // [64]
     double* stat = red + 64;                       // [16] scalars of the last check: pri, dua, rho estimate, scales (they are
                                                    //      read again only at the next check / the exit: LDS, not registers)
+    double* rhoL = stat + 16;                      // [32] the rho ladder (read at every check: LDS, not a global load)
     static_assert(NW * M <= NW * CW * RS, "part aliases the reduce slabs");
 
     const int n = a.n, m = a.m, ldn = a.ldn;
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         Hs[i] = (row < n && col < n) ? Ht[(size_t)col * ldn + row] : 0.0;      // Ht = sym(H): H[row][col] = Ht[col][row]
     }
     int ri = a.rho_ind[b];
+    if (tid < 32) rhoL[tid] = (tid < a.nrho) ? a.rhos[tid] : 0.0;   // (nrho <= 32: rqp_res64_fits)
     double kr[KC];
     auto load_K = [&](int j) {
         const int krow = CW * wave + rr;
@@ -419,9 +421,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
             const int ri_before = ri;
             residuals();                                              // :220 (Q4: carried estimate)
             const double pri = stat[0], dua = stat[1], rho_est = stat[2];
-            if (rho_est > a.rhos[ri] * a.tol && ri < a.nrho - 1)      // :223
+            if (rho_est > rhoL[ri] * a.tol && ri < a.nrho - 1)        // :223
                 ri += 1;
-            else if (rho_est < a.rhos[ri] / a.tol && ri > 0)          // :226
+            else if (rho_est < rhoL[ri] / a.tol && ri > 0)            // :226
                 ri -= 1;
             if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && tid == 0) {
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     if (tid == 0) a.rho_ind[b] = keep ? ri : a.rho_ind0;
 }
 
-bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N && h->m <= R64_M; }
+bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N && h->m <= R64_M && h->nrho <= 32; }
 
 hipError_t rqp_prepare_res64(const rqp_handle* h) {
     const int lds = (int)(r64_lds_doubles() * sizeof(double));

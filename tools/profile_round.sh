@@ -19,4 +19,5 @@ run_stats resident64 --precision f64
 bash tools/pmc_collect.sh ${R}_resident2 k_admm_res2 -- > $OUT/pmc_resident2.log 2>&1 && cp gpurun_out/pmc_${R}_resident2/pmc.json $OUT/pmc_resident2.json
 bash tools/pmc_collect.sh ${R}_mfma k_admm_mfma -- --workload mpc > $OUT/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_${R}_mfma/pmc.json $OUT/pmc_mfma.json
 bash tools/pmc_collect.sh ${R}_wave k_admm_wave -- --workload c4 > $OUT/pmc_wave.log 2>&1 && cp gpurun_out/pmc_${R}_wave/pmc.json $OUT/pmc_wave.json
+bash tools/pmc_collect.sh ${R}_resident64 k_admm_res64 -- --precision f64 > $OUT/pmc_resident64.log 2>&1 && cp gpurun_out/pmc_${R}_resident64/pmc.json $OUT/pmc_resident64.json
 ls -la $OUT
