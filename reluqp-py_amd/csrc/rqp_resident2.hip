@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 //   Hpack[mat][c][t][4]                     = H[HR*pl + 0..3][CW*w + CQ*q + c]
 //   KH: Kpack holds fp16 pairs (one dword per row pair) of K_j / Kscale[mat][j], Kscale = 2^e with max|K_j| / Kscale <= 2^14
 template <class C, bool KH>
-__global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
+__global__ void k_pack_res2(int n, int m, int ldn, int nrho, int xoff, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
                             float* __restrict__ Hpack, float* __restrict__ Kscale) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR;
@@ -693,8 +693,12 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
     const float* Hm = Ht + (size_t)mat * n * ldn;
     // every source matrix passes through LDS: coalesced row reads in, the lane-linear gather runs on LDS (the direct
     // gather from global memory was 4-byte accesses 52 B or a whole row apart: 5 ms per 4096 instances)
-    extern __shared__ __attribute__((aligned(16))) float stage[];        // max(m, n) * ldn floats
-    if (blockIdx.x == 0) {
+    // Two launches: the (A, H) blocks (xoff = 0, stage = max(m, n) * ldn floats: 125 KB at m = 300, one workgroup per CU) and
+    // the nrho K_j blocks per matrix (xoff = 1, stage = n * ldn floats: 3 workgroups per CU -- launched together with the
+    // big stage they ran one per CU as well: 2.6 ms for 4096 x 18 matrices)
+    extern __shared__ __attribute__((aligned(16))) float stage[];
+    const int bx = blockIdx.x + xoff;
+    if (bx == 0) {
         for (int i = t; i < m * ldn; i += NT) stage[i] = Am[i];
         __syncthreads();
         f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
@@ -719,7 +723,7 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, const float* __rest
             Hp[(size_t)c0 * NT + t] = (float4){hv[0], hv[1], hv[2], hv[3]};
         }
     } else {
-        const int j = blockIdx.x - 1;
+        const int j = bx - 1;
         const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
         for (int i = t; i < n * ldn; i += NT) stage[i] = Kj[i];
         __syncthreads();
@@ -789,14 +793,19 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
 
 template <class C>
 static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
-    dim3 grid(1 + h->nrho, h->nmat);
-    const size_t stage = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
-    if (h->dims.tile_dtype == RQP_TILE_F16)
-        k_pack_res2<C, true><<<grid, C::NT, stage, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
-                                                    (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
-    else
-        k_pack_res2<C, false><<<grid, C::NT, stage, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht,
-                                                     (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+    const size_t stage_ah = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
+    const size_t stage_k = (size_t)h->n * h->ldn * sizeof(float);
+    if (h->dims.tile_dtype == RQP_TILE_F16) {
+        k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->nrho, 0, (const float*)h->A, (const float*)h->Ht,
+                                                                     (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
+        k_pack_res2<C, true><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
+                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
+    } else {
+        k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->nrho, 0, (const float*)h->A, (const float*)h->Ht,
+                                                                      (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+        k_pack_res2<C, false><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
+                                                                           (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+    }
     return hipGetLastError();
 }
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
