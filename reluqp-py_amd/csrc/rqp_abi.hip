@@ -1,5 +1,6 @@
 // rqp_abi.hip -- the extern "C" boundary declared in include/rqp_abi.h.
 // Host orchestration only: argument validation, workspace ownership, kernel dispatch.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -299,6 +300,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     if (!H || !g || !A || !l || !u) return fail_arg(h, "rqp_setup: null input pointer");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->device));
+    const auto t_begin = std::chrono::steady_clock::now();
     free_ws(h);
     {
         const int rc = select_kernels(h);
@@ -369,6 +371,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->Esc, nm * m * sizeof(double)));
         HIP_TRY(h, hipMalloc((void**)&h->csc, nm * sizeof(double)));
     }
+    const auto t_alloc = std::chrono::steady_clock::now();
     int rc = build_matrices(h, a, s);
     if (rc != RQP_OK) {
         free_ws(h);
@@ -376,7 +379,16 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     }
     if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_scale_vecs(h, h->g, h->l, h->u, s));    // g <- c D g, l/u <- E l/u
     h->is_setup = true;
-    return rqp_clear_primal_dual(h, stream);    // zero state, rho_ind0 (reluqpth.py:148-153)
+    rc = rqp_clear_primal_dual(h, stream);      // zero state, rho_ind0 (reluqpth.py:148-153)
+    if (h->debug & 1) {                         // host-side split of a setup call (synchronous, debug only)
+        const auto t_enq = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(s);
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](auto a0, auto a1) { return std::chrono::duration<double, std::milli>(a1 - a0).count(); };
+        fprintf(stderr, "[rqp] setup host split: allocate %.2f ms, enqueue %.2f ms, device drain %.2f ms\n", ms(t_begin, t_alloc),
+                ms(t_alloc, t_enq), ms(t_enq, t_end));
+    }
+    return rc;
 }
 
 int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream) {
