@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int R64_NT = 512, R64_NW = 8, R64_CW = 13, R64_RL = 5, R64_N = 104, R64_M = 320, R64_KC = 26;
+constexpr int R64_PS = 10;                         // doubles per row of the A dx partials: 8 waves + 2 (16-byte rows, conflict-free b128 reads)
 constexpr int R64_RS = 66;                         // stride (doubles) of a column's 64 lane partials in the reduce slab
 constexpr size_t r64_lds_doubles() {
     return (size_t)R64_N * R64_N                   // Hs [col][row]
@@ -111,7 +112,8 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     extern __shared__ __attribute__((aligned(16))) double sm64[];
     double* Hs = sm64;                             // [N][N]: Hs[col * N + row]
     double* slab = Hs + N * N;                     // [NW][CW][RS]
-    double* part = slab;                           // [NW][M]  (alias: the slabs are dead between the K product and the next A' nu)
+    double* part = slab;                           // [M][PS]: the 8 wave partials of a row side by side (alias: the slabs are dead
+                                                   //          between the K product and the next A' nu)
     double* nuL = slab + NW * CW * RS;             // [M]
     double* loL = nuL + M;                         // [M] l  (row bounds wait in LDS: the register file is full of A and K)
     double* hiL = loL + M;                         // [M] u
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     double* stat = red + 64;                       // [16] scalars of the last check: pri, dua, rho estimate, scales (they are
                                                    //      read again only at the next check / the exit: LDS, not registers)
     double* rhoL = stat + 16;                      // [32] the rho ladder (read at every check: LDS, not a global load)
-    static_assert(NW * M <= NW * CW * RS, "part aliases the reduce slabs");
+    static_assert(M * R64_PS <= NW * CW * RS && NW <= R64_PS && N % 2 == 0, "part aliases the reduce slabs");
 
     const int n = a.n, m = a.m, ldn = a.ldn;
     const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
             for (int r = 0; r < RL; ++r) s[r] = fma(ar[r][c], vc, s[r]);
         }
 #pragma unroll
-        for (int r = 0; r < RL; ++r) part[wave * M + RL * lane + r] = s[r];
+        for (int r = 0; r < RL; ++r) part[(RL * lane + r) * R64_PS + wave] = s[r];
     };
     // [USE_A: A' w] + [USE_H: H xL] for the wave's own columns; lanes (c = lane >> 2 < 13, cc == 0) return the column sum
     auto prod_At = [&](bool use_a, bool use_h, const double* w) -> double {
@@ -218,11 +220,17 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
 #pragma unroll
             for (int r = 0; r < RL; ++r) wr[r] = w[RL * lane + r];
         }
-        // H rows of this lane: lane and lane + 64 (clamped: the multiplier of a row past N is 0 -- no divergent branch, so
-        // the LDS reads of a chunk can be requested together)
-        const int hr1 = (lane + 64 < N) ? lane + 64 : N - 1;
-        const double x0 = use_h ? xL[lane] : 0.0;                      // lane < 64 <= N
-        const double x1 = (use_h && lane + 64 < N) ? xL[hr1] : 0.0;
+        // H rows of this lane: 2 lane and 2 lane + 1 (lanes < 52), ONE ds_read_b128 per column.  (Rows lane and lane + 64 were
+        // merged by the compiler into ds_read2_b64 across columns: 8 LDS cycles for what two ds_read_b64 or one ds_read_b128
+        // do in 4 -- MI355X_MICROARCH.md, LDS table -- in the segment that runs at the LDS rate.)  Lanes >= 52 re-read the
+        // last row pair with a zero multiplier: no divergent branch, so the reads of a chunk are requested together.
+        const int hrow = (2 * lane + 1 < N) ? 2 * lane : N - 2;
+        double x0 = 0.0, x1 = 0.0;
+        if (use_h && 2 * lane + 1 < N) {
+            const double2 xv = *(const double2*)(xL + hrow);
+            x0 = xv.x;
+            x1 = xv.y;
+        }
         // columns in three chunks (4 + 4 + 5 accumulators live instead of 13: the register file is full of A and K)
         auto chunk = [&](auto c0c, auto c1c) __attribute__((always_inline)) {
             constexpr int C0 = decltype(c0c)::value, C1 = decltype(c1c)::value;
@@ -238,9 +246,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
             if (use_h) {
 #pragma unroll
                 for (int c = C0; c < C1; ++c) {
-                    const double* hc = Hs + (size_t)(CW * wave + c) * N;
-                    cs[c - C0] = fma(hc[lane], x0, cs[c - C0]);
-                    cs[c - C0] = fma(hc[hr1], x1, cs[c - C0]);
+                    const double2 hv = *(const double2*)(Hs + (size_t)(CW * wave + c) * N + hrow);
+                    cs[c - C0] = fma(hv.x, x0, cs[c - C0]);
+                    cs[c - C0] = fma(hv.y, x1, cs[c - C0]);
                 }
             }
 #pragma unroll
@@ -255,25 +263,33 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         double s = 0.0;
         if (rr < CW) {
             const double* src = sl + rr * RS + 16 * cc;
+            double s0 = 0.0, s1 = 0.0;                                // two chains of 8
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += src[k];
+            for (int k = 0; k < 16; k += 2) {
+                s0 += src[k];
+                s1 += src[k + 1];
+            }
+            s = s0 + s1;
         }
         return quad_sum(s);
     };
     // lanes cc == 0 get sum_c K[13 w + rr][c] v[c]
     auto prod_K = [&](const double* v) -> double {
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0;                                    // two chains: the 26 FMAs of a lane are one dependent chain otherwise
 #pragma unroll
-        for (int c = 0; c < KC; ++c) s = fma(kr[c], v[KC * cc + c], s);
-        return quad_sum(s);
+        for (int c = 0; c < KC; c += 2) {
+            s0 = fma(kr[c], v[KC * cc + c], s0);
+            s1 = fma(kr[c + 1], v[KC * cc + c + 1], s1);
+        }
+        return quad_sum(s0 + s1);
     };
     // row update.  do_a: A x += sum of the 8 wave partials; z = clamp(A x + lam / rho).  do_b: lam_hat, nu of the NEXT iteration.
     auto row_pass = [&](bool init, bool do_a, bool do_b) {
         if (!rown) return;
         if (init || do_a) {
-            double s = part[tid];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) s += part[w * M + tid];
+            const double2* pp = (const double2*)(part + tid * R64_PS);   // 4 ds_read_b128 (ds_read2st64_b64 pairs cost twice that)
+            const double2 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            const double s = ((p0.x + p0.y) + (p1.x + p1.y)) + ((p2.x + p2.y) + (p3.x + p3.y));   // fixed pairwise order
             zt = (init ? 0.0 : zt) + s;
         }
         if (do_a) {
