@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "rqp_common.h"
+#include "rqp_lanes.h"
 
 namespace {
 
@@ -44,57 +45,6 @@ __device__ __forceinline__ double dpp_add64(double v) {
 __device__ __forceinline__ double quad_sum(double v) {     // sum over the 4 lanes of a quad, every lane gets it
     v = dpp_add64<0xB1>(v);                                // quad_perm [1,0,3,2]
     return dpp_add64<0x4E>(v);                             // quad_perm [2,3,0,1]
-}
-
-// wave-wide reductions of the checks, in registers (DPP inside a row of 16 lanes, v_permlane16/32_swap across rows; the
-// swaps as inline asm with the 2 wait states a VALU-written operand needs -- see rqp_resident2.hip)
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_max64(double v) {                  // max(v, v of the DPP partner); NaN-free inputs
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)u), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(u >> 32));
-    return fmax(v, __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ void swap16(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(int& a, int& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ double rows_max64(double v) {                 // max over the 4 rows of 16 lanes, same lane of each row
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    int alo = (int)(unsigned)u, blo = alo, ahi = (int)(unsigned)(u >> 32), bhi = ahi;
-    swap16(alo, blo);
-    swap16(ahi, bhi);
-    double x = fmax(__builtin_bit_cast(double, ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo),
-                    __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo));
-    const unsigned long long w = __builtin_bit_cast(unsigned long long, x);
-    alo = (int)(unsigned)w; blo = alo; ahi = (int)(unsigned)(w >> 32); bhi = ahi;
-    swap32(alo, blo);
-    swap32(ahi, bhi);
-    return fmax(__builtin_bit_cast(double, ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo),
-                __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo));
-}
-__device__ __forceinline__ int rows_or(int v) {
-    int a = v, b = v;
-    swap16(a, b);
-    v = a | b;
-    a = v; b = v;
-    swap32(a, b);
-    return a | b;
-}
-__device__ __forceinline__ double wave_max64(double v) {                 // every lane gets the max over the 64 lanes
-    v = dpp_max64<0xB1>(v);                                            // quad_perm [1,0,3,2]
-    v = dpp_max64<0x4E>(v);                                            // quad_perm [2,3,0,1]
-    v = dpp_max64<0x141>(v);                                           // row_half_mirror
-    v = dpp_max64<0x140>(v);                                           // row_mirror
-    return rows_max64(v);
-}
-__device__ __forceinline__ int wave_or_i(int v) {
-    v |= dpp_i<0xB1>(v);
-    v |= dpp_i<0x4E>(v);
-    v |= dpp_i<0x141>(v);
-    v |= dpp_i<0x140>(v);
-    return rows_or(v);
 }
 
 template <typename U>

@@ -19,6 +19,7 @@
 // (rqp_admm.hip; reference line citations there); products in T (float: packed FMAs; double: the reference's default
 // precision, same layout with twice the registers), float64 state.
 #include "rqp_common.h"
+#include "rqp_lanes.h"
 
 namespace {
 
@@ -54,12 +55,6 @@ struct WOcc {
 template <typename T>
 __device__ __forceinline__ T wtmax(T a, T b) {                        // torch.max / norm(inf): NaN propagates
     return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
-}
-template <typename T>
-__device__ __forceinline__ T wave_tmax(T v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = wtmax(v, (T)__shfl_xor(v, off, 64));
-    return v;
 }
 
 }   // namespace
@@ -160,15 +155,34 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
             __builtin_amdgcn_wave_barrier();
         }
     };
-    // maximum over the whole instance (all waves); every lane gets it
-    auto inst_tmax = [&](T v, int slot) __attribute__((always_inline)) {
-        v = wave_tmax(v);
+    // The 7 maxima of a check over the whole instance (all waves), NaN-propagating like torch.max / norm(inf); every lane gets
+    // them.  In registers (rqp_lanes.h): the NaN flags travel as a bit mask, the values through v_max -- the shuffle version
+    // (6 ds_bpermute levels per value, the NaN selects as exec-masked branches) was a fifth of the kernel's instructions.
+    auto inst_tmax7 = [&](T (&v)[7]) __attribute__((always_inline)) {
+        int nanm = 0;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) nanm |= (v[e] != v[e]) ? (1 << e) : 0;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) v[e] = lanes_max(v[e]);
+        nanm = wave_or_i(nanm);
         if constexpr (NWV > 1) {
-            if (lane == 0) redL[wv][slot] = v;
+            if (lane == 0) {
+#pragma unroll
+                for (int e = 0; e < 7; ++e) redL[wv][e] = v[e];
+                redL[wv][7] = (T)nanm;                                   // (a small integer: exact in T)
+            }
             __syncthreads();
-            v = wtmax(redL[0][slot], redL[1][slot]);
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const T o0 = redL[0][e], o1 = redL[1][e];
+                v[e] = o0 > o1 ? o0 : o1;                                 // (NaN-free: a wave maximum that was all NaN is in the mask)
+                if (o1 != o1) v[e] = o0;
+            }
+            nanm = (int)redL[0][7] | (int)redL[1][7];
         }
-        return v;
+#pragma unroll
+        for (int e = 0; e < 7; ++e)
+            if ((nanm >> e) & 1) v[e] = (T)__builtin_nan("");
     };
     auto all_parts = [&](T v) __attribute__((always_inline)) {          // sum over the HALF parts of a column
         if constexpr (HALF == 2) v += (T)__shfl_xor(v, 32, 64);
@@ -206,13 +220,9 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
         handoff();
         const T t3 = all_parts(fold(at_times(zero2)));                  // A' lam
         hx = all_parts(fold(h_times(zero2)));                           // H x
-        const T v0 = inst_tmax(w0, 0);
-        const T v1 = inst_tmax(w1, 1);
-        const T v2 = inst_tmax(w2, 2);
-        const T v3 = inst_tmax((T)fabs(hx + t3 + gc), 3);
-        const T v4 = inst_tmax((T)fabs(hx), 4);
-        const T v5 = inst_tmax((T)fabs(t3), 5);
-        const T v6 = inst_tmax((T)fabs(gc), 6);
+        T v[7] = {w0, w1, w2, (T)fabs(hx + t3 + gc), (T)fabs(hx), (T)fabs(t3), (T)fabs(gc)};
+        inst_tmax7(v);
+        const T v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4], v5 = v[5], v6 = v[6];
         if constexpr (NWV > 1) __syncthreads();                         // redL is reused by the next check
         o_pri = v0;
         o_dua = v3;
