@@ -70,6 +70,20 @@ __device__ __forceinline__ float wave_max32(float v) {
 }
 __device__ __forceinline__ double lanes_max(double v) { return wave_max64(v); }
 __device__ __forceinline__ float lanes_max(float v) { return wave_max32(v); }
+// v + (v of lane ^ 32), every lane: one v_permlane32_swap instead of a ds_bpermute round trip
+__device__ __forceinline__ float xor32_sum(float v) {
+    int a = __builtin_bit_cast(int, v), b = a;
+    swap32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int alo = (int)(unsigned)u, blo = alo, ahi = (int)(unsigned)(u >> 32), bhi = ahi;
+    swap32(alo, blo);
+    swap32(ahi, bhi);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo) +
+           __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo);
+}
 __device__ __forceinline__ int wave_or_i(int v) {
     v |= dpp_i<0xB1>(v);
     v |= dpp_i<0x4E>(v);

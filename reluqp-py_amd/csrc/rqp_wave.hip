@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
             if ((nanm >> e) & 1) v[e] = (T)__builtin_nan("");
     };
     auto all_parts = [&](T v) __attribute__((always_inline)) {          // sum over the HALF parts of a column
-        if constexpr (HALF == 2) v += (T)__shfl_xor(v, 32, 64);
+        if constexpr (HALF == 2) v = xor32_sum(v);                      // (lanes 32 apart hold the two parts: a + b, either order)
         return v;
     };
 
@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
         return est;
     };
 
+    int to_chk = a.check_interval;                                      // iterations until k % check_interval == 0
     for (int k = 1; k <= kmax; ++k) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {                                  // row role: lam_hat, nu
@@ -265,7 +266,8 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
             z[q] = zn;
         }
         iters = k;
-        if ((k % a.check_interval) == 0) {                              // :218 (Q3 fixed: always check)
+        if (--to_chk == 0) {                                            // k % check_interval == 0, :218 (Q3 fixed: always check)
+            to_chk = a.check_interval;
             const int ri_before = ri;
             rho_est = residuals(rho_est, pri, dua);                     // :220 (Q4: estimate is carried)
             if (rho_est > (T)a.rhos[ri] * tolT && ri < a.nrho - 1)                // :223
