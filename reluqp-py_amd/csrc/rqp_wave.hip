@@ -128,13 +128,19 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
 
     // products: column role reads by-row vectors (nuL) / by-column vectors (xL, dL); row role reads dxL
     auto dot = [&](const pair* M, int len, const T* vec, pair acc) __attribute__((always_inline)) {   // acc + sum M[j] vec[j], pairwise
+        // two accumulator pairs, alternating: one chain left a hazard s_nop between every two dependent v_pk_fma_f32
+        pair acc1 = {(T)0, (T)0};
 #pragma unroll
         for (int q = 0; q < len / W; ++q) {
             const chunk v = *(const chunk*)(vec + W * q);
 #pragma unroll
-            for (int e = 0; e < PW; ++e) acc = __builtin_elementwise_fma(M[q * PW + e], (pair){v[2 * e], v[2 * e + 1]}, acc);
+            for (int e = 0; e < PW; ++e) {
+                const pair ve = {v[2 * e], v[2 * e + 1]};
+                if ((q * PW + e) & 1) acc1 = __builtin_elementwise_fma(M[q * PW + e], ve, acc1);
+                else acc = __builtin_elementwise_fma(M[q * PW + e], ve, acc);
+            }
         }
-        return acc;
+        return acc + acc1;
     };
     const pair zero2 = {(T)0, (T)0};
     auto at_times = [&](pair acc) __attribute__((always_inline)) { return dot(Atc, AT, nuL + AT * h, acc); };   // + A[AT h..][c]' nu[AT h..]
