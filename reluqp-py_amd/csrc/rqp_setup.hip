@@ -416,36 +416,44 @@ __global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
 // of the headline batch).  Thread (ty, tx) of a 16 x 16 grid now owns the RT x RT elements (ty + 16 i, tx + 16 j): RT row
 // values for its rows and RT for its columns -- 2 RT reads for RT^2 FMAs (n <= 16 RT; RT = 7: 14 reads for 49 FMAs) --
 // and the column-k / row-k fix-ups touch RT elements instead of R: 7.6 ms.
+// The sweep keeps M symmetric, so only the blocks (i, j) with i <= j of a thread are stored and updated (RT = 7: 28 of 49
+// FMAs per step, 56 instead of 98 matrix registers -> 4 workgroups per CU): element (r, c) of a lower block is element
+// (c, r) of thread (tx, ty)'s upper block.  Row k is posted by its two sets of owners: the threads with ty == ko hold
+// (k, c) for the blocks j >= kb, the threads with tx == ko hold (c, k) = (k, c) for the blocks i < kb.  [7.6 -> ms below]
 template <typename T, int RT>
-__global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
+__global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     constexpr int NMAX = 16 * RT;
     __shared__ __attribute__((aligned(16))) double rowbuf[2][NMAX];
-    __shared__ __attribute__((aligned(16))) double tb[RT][16][17];       // one symmetrisation pass: RT blocks, closed under transposition
+    __shared__ __attribute__((aligned(16))) double tb[RT][16][17];       // one output pass: RT blocks, closed under transposition
     const int n = a.n;
     const int mat = blockIdx.x / a.nrho, jrho = blockIdx.x % a.nrho;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
     const double rho = a.rhos[jrho];
-    double mreg[RT][RT];
+    double mreg[RT][RT];                                                  // blocks i <= j only
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
+        for (int j = i; j < RT; ++j) {
             const int r = ty + 16 * i, c = tx + 16 * j;
             mreg[i][j] = 0.0;
             if (r < n && c < n) mreg[i][j] = (double)Ht[(size_t)r * a.ldn + c] + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
         }
-    // (every thread divides by the pivot after the barrier: letting only the 16 owners of row k divide -- they would post
+    // (every thread divides by the pivot after the barrier: letting only the owners of row k divide -- they would post
     //  row / d as well -- puts a cross-lane fetch of d and the division in front of the barrier: 8.9 ms instead of 7.6)
     auto step = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if (k < n) {                                                      // uniform
             constexpr int kb = k / 16, ko = k % 16;                       // row / column block and offset of the pivot
             double* rb = rowbuf[k & 1];
-            if (ty == ko) {                                               // owners of row k: RT values each
+            if (ty == ko) {                                               // (k, c) for c in the blocks j >= kb
 #pragma unroll
-                for (int j = 0; j < RT; ++j) rb[tx + 16 * j] = mreg[kb][j];
+                for (int j = kb; j < RT; ++j) rb[tx + 16 * j] = mreg[kb][j];
+            }
+            if (tx == ko) {                                               // (k, c) = (c, k) for c in the blocks i < kb
+#pragma unroll
+                for (int i = 0; i < kb; ++i) rb[ty + 16 * i] = mreg[i][kb];
             }
             __syncthreads();
             // 1 / d: hardware reciprocal + two Newton steps (5 instructions; the IEEE division sequence is ~15, and every
@@ -464,34 +472,42 @@ __global__ void __launch_bounds__(256, 3) k_factor_reg2(SetupArgs a) {
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < RT; ++j) mreg[i][j] = fma(rr[i], tc[j], mreg[i][j]);
+                for (int j = i; j < RT; ++j) mreg[i][j] = fma(rr[i], tc[j], mreg[i][j]);
             if (tx == ko) {                                               // column k: row[r] / d
 #pragma unroll
-                for (int i = 0; i < RT; ++i) mreg[i][kb] = rr[i] * p;
+                for (int i = 0; i <= kb; ++i) mreg[i][kb] = rr[i] * p;
             }
             if (ty == ko) {                                               // row k: row[c] / d ; pivot: -1 / d
 #pragma unroll
-                for (int j = 0; j < RT; ++j) mreg[kb][j] = -tc[j];
+                for (int j = kb; j < RT; ++j) mreg[kb][j] = -tc[j];
                 if (tx == ko) mreg[kb][kb] = -p;
             }
         }
     };
     rqp_static_for(std::make_integer_sequence<int, NMAX>{}, step);
-    // K_j = -(M + M')/2: block (i, j) of thread (ty, tx) meets block (j, i) of thread (tx, ty) through LDS; pass d moves the
-    // RT blocks with (i + j) mod RT == d (a set closed under transposition), slot i = block (i, (d - i) mod RT)
+    // K_j = -M.  Pass d moves the RT blocks with (i + j) mod RT == d (a set closed under transposition), slot i = block
+    // (i, (d - i) mod RT): an upper block comes from the thread's own registers, a lower block (i, j), i > j, is the
+    // transpose of block (j, i) of thread (tx, ty) -- slot j of the same pass -- and a diagonal block averages the two
+    // roundings of (r, c) and (c, r), which both exist there.
     T* K = (T*)a.K + ((size_t)mat * a.nrho + jrho) * n * a.ldn;
 #pragma unroll
-    for (int d = 0; d < RT; ++d) {                                        // pass d: blocks with (i + j) % RT == d (closed under transposition)
+    for (int d = 0; d < RT; ++d) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RT; ++i) tb[i][ty][tx] = mreg[i][(d - i + RT) % RT];
+        for (int i = 0; i < RT; ++i) {
+            const int j = (d - i + RT) % RT;
+            if (i <= j) tb[i][ty][tx] = mreg[i][j];
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int j = (d - i + RT) % RT;
             const int r = ty + 16 * i, c = tx + 16 * j;
-            const double mt = tb[j][tx][ty];                              // M[c][r]: thread (tx, ty), block (j, i) = slot j of this pass
-            if (r < n && c < a.ldn) K[(size_t)r * a.ldn + c] = (c < n) ? (T)(-0.5 * (mreg[i][j] + mt)) : T(0);
+            double v;
+            if (i < j) v = mreg[i][j];
+            else if (i > j) v = tb[j][tx][ty];                            // M[c][r]: thread (tx, ty), block (j, i)
+            else v = 0.5 * (mreg[i][i] + tb[i][tx][ty]);
+            if (r < n && c < a.ldn) K[(size_t)r * a.ldn + c] = (c < n) ? (T)(-v) : T(0);
         }
     }
 }
