@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(256) k_gram(SetupArgs a) {
         }
 }
 
-// n <= 16 RT: one workgroup per matrix in the 16 x 16 x (RT x RT) register layout of k_factor_reg2: 2 RT LDS reads for
+// n <= 16 RT: one workgroup per matrix in the 16 x 16 x (RT x RT) register layout of k_factor_reg2 (upper blocks only,
+// like that kernel -- the lower blocks of G are never written nor read): 2 RT LDS reads for
 // RT^2 FMAs (the 64 x 64-tile kernel above spends 8 reads on 16 FMAs and pads n = 100 to two tiles per dimension).
 template <typename T, int RT>
 __global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
@@ -232,11 +233,11 @@ __global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const T* A = (const T*)a.A + (size_t)mat * m * a.ldn;
     const T* cv = (const T*)a.c + (size_t)mat * m;                       // shared mats: instance 0's pattern (mat = 0)
-    double acc[RT][RT];
+    double acc[RT][RT];                                                  // blocks i <= j only: k_factor_reg2 reads nothing else of G
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) acc[i][j] = 0.0;
+        for (int j = i; j < RT; ++j) acc[i][j] = 0.0;
     for (int k0 = 0; k0 < m; k0 += KB) {
         for (int e = tid; e < KB * NMAX; e += 256) {
             const int kk = e / NMAX, col = e % NMAX, k = k0 + kk;
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < RT; ++j) acc[i][j] = fma(rr[i], cc[j], acc[i][j]);
+                for (int j = i; j < RT; ++j) acc[i][j] = fma(rr[i], cc[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
+        for (int j = i; j < RT; ++j) {
             const int r = ty + 16 * i, c = tx + 16 * j;
             if (r < n && c < n) G[(size_t)r * n + c] = acc[i][j];
         }
@@ -278,7 +279,7 @@ hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t 
         if (h->esz == 4) k_gram2<float, 4><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 4><<<h->nmat, 256, 0, s>>>(a);
         return hipGetLastError();
     }
-    if (h->n <= 112) {
+    if (h->n <= 112 && h->ldn <= 112) {           // (the same predicate as rqp_launch_factor: k_factor_reg2 reads the upper blocks only)
         if (h->esz == 4) k_gram2<float, 7><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 7><<<h->nmat, 256, 0, s>>>(a);
         return hipGetLastError();
     }
