@@ -183,6 +183,8 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         for (int u = 0; u < HU; ++u) ((float4*)Hs)[u * NT + tid] = Hp[u * NT + tid];
     }
     int ri = a.rho_ind[b];
+    float* rhoL = red + 32;                               // [32] the rho ladder: read at every check (LDS, not a dependent global load)
+    if (tid < 32) rhoL[tid] = (tid < a.nrho) ? (float)a.rhos[tid] : 0.f;     // (nrho <= 32: res2_pick)
     typedef typename std::conditional<KH, h2, f2>::type kpair_t;      // a row pair of K: two floats, or two halves in one dword
     kpair_t kr[KP][KC];
     float kscale = 1.f;
@@ -585,9 +587,9 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
             rho_est = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rho_est)));
             pri = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pri)));
             dua = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dua)));
-            if (rho_est > (float)a.rhos[ri] * tolT && ri < a.nrho - 1)          // :223
+            if (rho_est > rhoL[ri] * tolT && ri < a.nrho - 1)                   // :223
                 ri += 1;
-            else if (rho_est < (float)a.rhos[ri] / tolT && ri > 0)              // :226
+            else if (rho_est < rhoL[ri] / tolT && ri > 0)                       // :226
                 ri -= 1;
             if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && tid == 0) {
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
@@ -766,7 +768,7 @@ typedef Res2Cfg<4, 7, 2, 7> Cfg2M;         // n <= 56,  m <= 128
 typedef Res2Cfg<10, 10, 4, 10> Cfg2N;      // n <= 80,  m <= 320   (condensed linear MPC, N = 20, nu = 4: n = 80, m = 320)
 
 static int res2_pick(const rqp_handle* h) {            // smallest tile that holds the problem; -1: none
-    if (h->esz != 4) return -1;
+    if (h->esz != 4 || h->nrho > 32) return -1;
     if (h->n <= Cfg2C4::N && h->m <= Cfg2C4::M) return 0;
     if (h->n <= Cfg2M::N && h->m <= Cfg2M::M) return 1;
     if (h->n <= Cfg2N::N && h->m <= Cfg2N::M) return 3;

@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     __shared__ __attribute__((aligned(16))) T dL[NCT];                 // d by column
     __shared__ __attribute__((aligned(16))) T dxL[NCT];                // dx by column
     __shared__ T redL[NWV][8];                                         // cross-wave maxima / sums (NWV > 1)
+    __shared__ T rhoL[32];                                             // the rho ladder: read at every check (LDS, not a dependent global load)
     const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x & 63;   // dispatch order: longest solve first
     const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int n = a.n, m = a.m, ldn = a.ldn, ldm = a.ldm;
@@ -103,6 +104,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     load_row(Atc, AT, At + (size_t)c * ldm + AT * h, cok, ldm - AT * h);     // rows AT h .. of column c
     load_row(Hc, KH, Ht + (size_t)c * ldn + KH * h, cok, ldn - KH * h);      // sym(H): row c = column c
     int ri = a.rho_ind[b];
+    if (threadIdx.x < 32) rhoL[threadIdx.x] = ((int)threadIdx.x < a.nrho) ? (T)a.rhos[threadIdx.x] : (T)0;   // (nrho <= 32: rqp_wave_fits)
     auto load_K = [&]() __attribute__((always_inline)) {
         load_row(Kc, KH, Kb + ((size_t)ri * n + c) * ldn + KH * h, cok, ldn - KH * h);
     };
@@ -276,9 +278,9 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
             to_chk = a.check_interval;
             const int ri_before = ri;
             rho_est = residuals(rho_est, pri, dua);                     // :220 (Q4: estimate is carried)
-            if (rho_est > (T)a.rhos[ri] * tolT && ri < a.nrho - 1)                // :223
+            if (rho_est > rhoL[ri] * tolT && ri < a.nrho - 1)                     // :223
                 ri += 1;
-            else if (rho_est < (T)a.rhos[ri] / tolT && ri > 0)                    // :226
+            else if (rho_est < rhoL[ri] / tolT && ri > 0)                         // :226
                 ri -= 1;
             if (a.info.trace && (k / a.check_interval) <= a.info.trace_cap && threadIdx.x == 0) {
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
@@ -341,6 +343,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
 
 // 0: does not fit; 1: <T, 32, 64>; 2: <float, 32, 128>; 3: <float, 32, 64, 2> (two wavefronts per instance)
 static int wave_class(const rqp_handle* h) {
+    if (h->nrho > 32) return 0;                     // (the ladder sits in a 32-entry LDS array)
     if (h->n <= 32 && h->m <= 64) return 1;
     if (h->esz == 4 && h->n <= 32 && h->m <= 128) return 2;
     // two wavefronts per instance: measured 0.72x the mid resident tile (n <= 56, m <= 128) but 1.96x the big tile, so it
