@@ -21,6 +21,7 @@ numpy accepted everywhere, per-instance info tensors in batch mode.
 Reference quirks are handled as listed in SURVEY.md Appendix B (DESIGN.md has the
 table): Q1/Q2/Q3/Q6/Q8/Q9/Q11/Q13/Q14 fixed, Q4/Q5/Q10/Q15/Q16/Q17 replicated.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -72,7 +73,11 @@ class ReLU_QP(object):
         return ctypes.c_void_p(torch.cuda.current_stream(self.settings.device).cuda_stream)
 
     def _events(self):
-        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # one pair per solver object, reused by every timed call (each call synchronises on the second before returning)
+        ev = getattr(self, "_ev_pair", None)
+        if ev is None:
+            ev = self._ev_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        return ev
 
     def _csettings(self):
         s = self.settings
@@ -95,6 +100,7 @@ class ReLU_QP(object):
         self._destroy()
 
     def _destroy(self):
+        self._ev_pair = None              # (events belong to the device of the handle)
         if getattr(self, "_shards", None):
             self._shards.destroy()
             self._shards = None
@@ -329,7 +335,11 @@ class ReLU_QP(object):
         lib = _cabi.load()
         st, qp = self.settings, self.QP
         dev, B, n, m = st.device, qp.batch, qp.nx, qp.nc
-        with torch.cuda.device(dev):
+        # (host cost of a call matters at small batches -- tools/solve_overhead.py: the device guard is entered only when
+        #  another device is current, and the current stream is looked up once for the launch and both event records)
+        guard = torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else contextlib.nullcontext()
+        with guard:
+            stream = torch.cuda.current_stream(dev)
             timed = self.synchronous
             xzl = torch.empty(B * (n + 2 * m), device=dev, dtype=st.precision)      # one allocation, three contiguous views
             x, z, lam = xzl[:B * n].view(B, n), xzl[B * n:B * (n + m)].view(B, m), xzl[B * (n + m):].view(B, m)
@@ -345,11 +355,11 @@ class ReLU_QP(object):
                              trace=trace.data_ptr() if trace is not None else None, trace_cap=cap, reserved=0)
             if timed:                    # one pair of HIP events around the launch: run_time = what the device spent
                 k0, k1 = self._events()
-                k0.record()
+                k0.record(stream)
             _cabi.check(self._h, lib.rqp_solve(self._h, _cabi.ptr(x), _cabi.ptr(z), _cabi.ptr(lam),
-                                               ctypes.byref(ci), self._stream()), "rqp_solve")
+                                               ctypes.byref(ci), ctypes.c_void_p(stream.cuda_stream)), "rqp_solve")
             if timed:
-                k1.record()
+                k1.record(stream)
                 k1.synchronize()
                 run_time = k0.elapsed_time(k1) / 1000.0
                 self.last_kernel_time = run_time                       # the ADMM launch (+ its order / un-scaling passes)
