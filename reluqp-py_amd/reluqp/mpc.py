@@ -253,8 +253,18 @@ class LinearMPC(object):
                 step()
             torch.cuda.current_stream(device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
+            # no finaliser may run while the stream is capturing: the capture mode is global, so a collected solver object
+            # (rqp_destroy -> hipFree) or tensor anywhere in the process would invalidate it (seen once in a long test session)
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph):
+                    step()
+            finally:
+                if gc_was_on:
+                    gc.enable()
             done = 1                                          # the warm-up ran one step (capturing only records)
             for _ in range(max(0, steps - done)):
                 graph.replay()
