@@ -486,13 +486,20 @@ def test_infeasibility_certificates(prec, kernel):
     assert float(st.abs().max()) == 0.0 and int(ri.min()) == int(ri.max()) == 7
 
 
-@pytest.mark.parametrize("kernel", ["generic", "wave", "resident"])
-def test_nan_status(kernel):
+@pytest.mark.parametrize("kernel,prec,shape,expect", [
+    ("generic", torch.float32, (12, 3, 17), "generic"), ("wave", torch.float32, (12, 3, 17), "wave"),
+    ("resident", torch.float32, (12, 3, 17), "resident2"),
+    # the register-level check reductions (rqp_lanes.h: NaN flags as a bit mask beside v_max): float64 wavefront kernel,
+    # float64 resident kernel, and the two-wavefront instantiation, whose maxima also cross waves through LDS
+    ("wave", torch.float64, (12, 3, 17), "wave"), ("resident", torch.float64, (12, 3, 17), "resident64"),
+    ("wave", torch.float32, (60, 10, 90), "wave")])
+def test_nan_status(kernel, prec, shape, expect):
     """A NaN in the data poisons the residuals: the reference keeps iterating and reports max_iters_reached with NaN
     residuals (Q17); the build labels it nan_detected (status code 2) -- same loop control, only the label differs."""
-    H, g, A, l, u, _ = utils.rand_qp_batch(3, 12, 3, 17, seed0=5, feasible=True)
+    H, g, A, l, u, _ = utils.rand_qp_batch(3, *shape, seed0=5, feasible=True)
     g[1, 4] = np.nan
-    m = _solver(H, g, A, l, u, precision=torch.float32, kernel=kernel, max_iter=75)
+    m = _solver(H, g, A, l, u, precision=prec, kernel=kernel, max_iter=75)
+    assert m.kernel == expect
     r = m.solve()
     st = list(r.info.status)
     assert st[1] == "nan_detected" and st[0] != "nan_detected" and st[2] != "nan_detected"
