@@ -127,3 +127,44 @@ def test_shared_matrix_batches_all_kernels_vs_oracle(n, n_eq, n_ineq, B, seed0, 
         td = st["eps_abs"] * np.sqrt(n) + st["eps_rel"] * np.maximum.reduce([np.abs(x @ H.T).max(axis=1), np.abs(y @ A).max(axis=1),
                                                                         np.abs(g).max(axis=1)])
         assert np.all(pri[solved] < 1.1 * tp[solved] + 1e-5 * scale) and np.all(dua[solved] < 1.1 * td[solved] + 2e-4 * scale), (m.kernel, pri, dua)
+
+
+@pytest.mark.parametrize("n,n_eq,n_ineq,seed0,warm", [(2, 0, 3, 11, True), (9, 2, 13, 12, True), (32, 8, 56, 13, False),
+                                                      (33, 5, 70, 14, True), (77, 19, 200, 15, True), (104, 26, 294, 16, False)])
+def test_update_sequences_float64_exact(n, n_eq, n_ineq, seed0, warm):
+    """setup -> solve -> update(g, l, u) -> solve -> update(Hx, Ax) -> solve -> update(g) -> solve on every float64 kernel that
+    holds the shape: the same iteration counts as the oracle at every step (state and rho index carried or cleared as
+    warm_starting says), x to 1e-8.  (n = 1 is left to the single-solve sweep above: its residuals hit exact zeros, where the
+    reference's rho estimate is 0/0 and a rounding-level difference picks another rho index for the warm-started re-solves.)"""
+    import reluqp.reluqpth as reluqpth
+    H, g, A, l, u, _ = utils.rand_qp(n, n_eq, n_ineq, seed=seed0, compute_sol=False, feasible=True)
+    _, g2, _, l2, u2, _ = utils.update_qp(H, A, n_eq, n_ineq, seed=seed0 + 100, compute_sol=False, feasible=True)
+    rs = np.random.RandomState(seed0)
+    H3 = H + 0.05 * np.diag(rs.rand(n))
+    A3 = A * (1.0 + 0.01 * rs.randn(*A.shape)) if n_eq == 0 else A        # (equality rows stay consistent with l = u)
+    _, g4, _, _, _, _ = utils.update_qp(H, A, n_eq, n_ineq, seed=seed0 + 200, compute_sol=False, feasible=True)
+    st = dict(eps_abs=1e-4, warm_starting=warm)
+
+    def run(solver, tonp):
+        out = []
+        out.append(tonp(solver.solve()))
+        solver.update(g=g2, l=l2, u=u2)
+        out.append(tonp(solver.solve()))
+        solver.update(Hx=H3, Ax=A3)
+        out.append(tonp(solver.solve()))
+        solver.update(g=g4)
+        out.append(tonp(solver.solve()))
+        return out
+
+    qp = O.OracleQP(form="factored")
+    qp.setup(H, g, A, l, u, **st)
+    ref = run(qp, lambda r: (int(r.info.iter), r.info.status, np.array(r.x, copy=True)))
+    for kernel in ("generic", "resident", "wave"):
+        if not _fits(kernel, n, n_eq + n_ineq):
+            continue
+        m = reluqpth.ReLU_QP()
+        m.setup(H, g, A, l, u, device=DEV, precision=torch.float64, kernel=kernel, **st)
+        got = run(m, lambda r: (int(r.info.iter), r.info.status, r.x.cpu().numpy().copy()))
+        for step, ((it, stat, x), (rit, rstat, rx)) in enumerate(zip(got, ref)):
+            assert (it, stat) == (rit, rstat), (m.kernel, step, it, stat, rit, rstat)
+            np.testing.assert_allclose(x, rx, rtol=0, atol=1e-8 * max(1.0, float(np.abs(rx).max())), err_msg="%s step %d" % (m.kernel, step))
