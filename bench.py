@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--kernel", default="auto", help="C-ABI kernel request (auto | generic | resident | wave | mfma)")
     ap.add_argument("--tile", choices=["same", "f16"], default="same", help="K(rho) tile storage (BASELINE config 5: f16)")
+    ap.add_argument("--low-memory", action="store_true", help="setup(low_memory=True): no packed copy of K(rho) (less workspace "
+                    "and setup time, ~1 %% more solve time; not the default)")
     ap.add_argument("--workload", choices=["random_qp", "mpc", "c4"], default="random_qp",
                     help="random_qp: the headline metric's workload (default); mpc: BASELINE config 3, batch of condensed "
                          "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A; c4: BASELINE config 4, "
@@ -239,7 +241,7 @@ def main():
     model = reluqpth.ReLU_QP()
     t0 = time.perf_counter()
     model.setup(Hd, gd, Ad, ld, ud, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False, kernel=args.kernel,
-                iterate_dtype=torch.float16 if args.tile == "f16" else None)
+                iterate_dtype=torch.float16 if args.tile == "f16" else None, low_memory=args.low_memory)
     torch.cuda.synchronize(dev)
     setup_s = time.perf_counter() - t0
 
@@ -322,7 +324,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl,
                        "global_batch": int(tot_qps), "parallelism": "batch-split x%d, no collectives" % world,
-                       "kernel": model.kernel, "tile": args.tile},
+                       "kernel": model.kernel, "tile": args.tile, "low_memory": bool(args.low_memory)},
             "admm_iters_per_sec": tot_iters / step_s,
             "mean_iters": tot_iters / tot_qps,
             "solved_frac": tot_solved / tot_qps,

@@ -189,6 +189,9 @@ int select_kernels(rqp_handle* h) {
     // iterate / residuals modes of an MFMA or wave handle run on the resident tile when one fits, else on the streaming kernel
     if (h->use_mfma && rqp_res2_fits(h)) h->resident = true;
     if (h->dims.tile_dtype == RQP_TILE_F16 && !h->resident) return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel");
+    // RQP_FLAG_LOW_MEMORY: the float32 resident kernel reads K from the row-major table (no effect on the other kernels, which
+    // have no packed copy of it; the fp16 tile IS the smaller copy)
+    h->k_direct = (h->dims.flags & RQP_FLAG_LOW_MEMORY) && h->resident && h->dims.tile_dtype != RQP_TILE_F16;
     if (h->use_mfma) h->kernel_name = "mfma";
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
@@ -208,7 +211,7 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             size_t ae, ke, he;
             rqp_res2_pack_elems(h, &ae, &ke, &he);
             HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
-            HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));
+            if (ke) HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));   // (none with RQP_FLAG_LOW_MEMORY)
             HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
             if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
             HIP_TRY(h, rqp_prepare_res2(h));

@@ -46,6 +46,7 @@ struct rqp_handle {
     size_t fscratch_elems = 0;
     // resident kernel images (rqp_resident2.hip): lane-linear register / LDS layouts
     float *Apack = nullptr, *Kpack = nullptr, *Hpack = nullptr;
+    bool k_direct = false;        // RQP_FLAG_LOW_MEMORY on the float32 resident kernel: no Kpack, K read from the row-major table
     float* Kscale = nullptr;      // [nmat][nrho] power-of-two scale of the fp16 K tile (tile_dtype = RQP_TILE_F16)
     bool resident = false;        // rqp_resident2.hip: A, K in VGPRs (solve, iterate and residuals modes)
     bool resident64 = false;      // rqp_res64.hip: the float64 resident kernel (n <= 104, m <= 320), all modes

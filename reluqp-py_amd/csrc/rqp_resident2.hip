@@ -117,7 +117,7 @@ struct Res2Cfg {
 // KH = true: the K(rho) tile is stored as fp16 row pairs (rqp_dims.tile_dtype = RQP_TILE_F16, BASELINE config 5): half the
 // registers and half the reload bytes; products accumulate in float32 (v_fma_mix_f32 reads the half operand directly), the
 // per-(matrix, rho) power-of-two scale Kscale keeps the entries inside the fp16 range.  K only preconditions dx = -K d.
-template <class C, bool DIAG, bool KH>
+template <class C, bool DIAG, bool KH, bool KD = false>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs a, const float* __restrict__ Apack,
                                                       const float* __restrict__ Kpack,
                                                       const float* __restrict__ Hpack, unsigned long long* dbg,
@@ -188,13 +188,37 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     typedef typename std::conditional<KH, h2, f2>::type kpair_t;      // a row pair of K: two floats, or two halves in one dword
     kpair_t kr[KP][KC];
     float kscale = 1.f;
+    // KD (RQP_FLAG_LOW_MEMORY, float32 only): K straight from the row-major K(rho) table of the factor kernel (Kpack = NULL) --
+    // lane (rr, cc) takes the row pairs of its rows, columns KC cc .. KC cc + KC - 1: the 8 lanes of a row group read one
+    // whole row between them, so every cache line is fetched once.  No packed copy of the table (3.9 GB and 1.3 ms of setup
+    // at B = 4096); the guarded 4-byte loads make a K load ~2x slower, +0.9 % per solve (A/B, tools/ab_bench.sh).
     auto load_K = [&](int j) {
-        const kpair_t* Kp = (const kpair_t*)Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT + tid;
+        if constexpr (!KD) {
+            const kpair_t* Kp = (const kpair_t*)Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT + tid;
 #pragma unroll
-        for (int kp = 0; kp < KP; ++kp)
+            for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
-            for (int c = 0; c < KC; ++c) kr[kp][c] = Kp[(size_t)(kp * KC + c) * NT];
-        if constexpr (KH) kscale = Kscale[mat * a.nrho + j];
+                for (int c = 0; c < KC; ++c) kr[kp][c] = Kp[(size_t)(kp * KC + c) * NT];
+            if constexpr (KH) kscale = Kscale[mat * a.nrho + j];
+        } else {
+            // (lane-derived offsets through an opaque copy: otherwise the addresses and predicates of this rare path are
+            //  hoisted out of the solve loop and cost it registers)
+            int lane_o = lane, wave_o = wave;
+            asm volatile("" : "+v"(lane_o), "+v"(wave_o));
+            const int rr = lane_o >> 3, cc = lane_o & 7, wave = wave_o;
+            const float* Kj = (const float*)a.K + ((a.sK == 0) ? (size_t)0 : (size_t)b * a.sK) + (size_t)j * n * a.ldn;
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                const int lr = KR * rr + 2 * kp, r = CW * wave + lr;
+                const bool ok0 = lr < CW && r < n, ok1 = lr + 1 < CW && r + 1 < n;
+                const float* row0 = Kj + (size_t)r * a.ldn + KC * cc;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const bool cin = KC * cc + c < n;
+                    kr[kp][c] = (f2){(ok0 && cin) ? row0[c] : 0.f, (ok1 && cin) ? row0[a.ldn + c] : 0.f};
+                }
+            }
+        }
     };
     load_K(ri);
 
@@ -781,7 +805,7 @@ bool rqp_res2_fits(const rqp_handle* h) { return res2_pick(h) >= 0; }
 template <class C>
 static void pack_elems_t(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
     *a_elems = (size_t)h->nmat * C::AE2 * C::NT * 2;
-    *k_elems = (size_t)h->nmat * h->nrho * C::KE2 * C::NT * (h->dims.tile_dtype == RQP_TILE_F16 ? 1 : 2);
+    *k_elems = h->k_direct ? 0 : (size_t)h->nmat * h->nrho * C::KE2 * C::NT * (h->dims.tile_dtype == RQP_TILE_F16 ? 1 : 2);
     *h_elems = (size_t)h->nmat * C::HU * C::NT * 4;
 }
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
@@ -805,8 +829,9 @@ static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
     } else {
         k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->nrho, 0, (const float*)h->A, (const float*)h->Ht,
                                                                       (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
-        k_pack_res2<C, false><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
-                                                                           (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+        if (!h->k_direct)       // (low-memory handles read K from the row-major table: only the (A, H) images)
+            k_pack_res2<C, false><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
+                                                                               (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
     }
     return hipGetLastError();
 }
@@ -833,6 +858,10 @@ static hipError_t prepare_t(const rqp_handle* h) {
         return hipFuncSetAttribute((const void*)k_admm_res2<C, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (h->k_direct) {
+        e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (h->debug & 2) e = hipFuncSetAttribute((const void*)k_admm_res2<C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (h->debug & 1) {
         int nb = -1;
@@ -860,7 +889,7 @@ static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s
         k_admm_res2<C, false, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr, h->Kscale);
         return hipGetLastError();
     }
-    if (h->debug & 2) {          // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
+    if ((h->debug & 2) && !h->k_direct) {   // diagnostic build: per-segment cycle shares of the iteration (synchronous, debug only)
         unsigned long long* dbg = nullptr;
         const size_t cnt = (size_t)h->B * 4 * 10;
         if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
@@ -883,7 +912,10 @@ static hipError_t solve_t(const rqp_handle* h, const SolveArgs& a, hipStream_t s
         }
         return hipGetLastError();
     }
-    k_admm_res2<C, false, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
+    if (h->k_direct)
+        k_admm_res2<C, false, false, true><<<h->B, C::NT, lds, s>>>(a, h->Apack, nullptr, h->Hpack, nullptr, nullptr);
+    else
+        k_admm_res2<C, false, false><<<h->B, C::NT, lds, s>>>(a, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
     return hipGetLastError();
 }
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

@@ -14,6 +14,7 @@ RQP_F32, RQP_F64 = 0, 1
 RQP_TILE_SAME, RQP_TILE_F16 = 0, 1
 KERNELS = {"auto": 0, "generic": 1, "resident": 2, "resident2": 2, "wave": 3, "mfma": 4}     # enum rqp_kernel
 RQP_ERR_UNSUPPORTED = -5
+FLAG_LOW_MEMORY = 1          # rqp_dims.flags
 STATUS_STR = {0: "solved", 1: "max_iters_reached", 2: "nan_detected", 3: "primal_infeasible", 4: "dual_infeasible",
               -1: "unsolved"}
 
@@ -39,7 +40,7 @@ class RqpError(RuntimeError):
 class Dims(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("m", ctypes.c_int32), ("batch", ctypes.c_int32),
                 ("shared_mats", ctypes.c_int32), ("dtype", ctypes.c_int32), ("kernel", ctypes.c_int32),
-                ("tile_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("tile_dtype", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class CSettings(ctypes.Structure):

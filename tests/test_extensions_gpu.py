@@ -635,3 +635,35 @@ def test_fp16_tile_survives_matrix_update():
     ref = O.solve_batch(H2, g * 40.0, A, l, u, form="factored", eps_abs=1e-9, max_iter=20000)
     assert all(s == "solved" for s in r.info.status)
     np.testing.assert_allclose(_np(r.x), ref["x"], rtol=0, atol=2e-2 * max(1.0, np.abs(ref["x"]).max()))
+
+
+# ------------------------------------------------------------------- low_memory (rqp_dims.flags RQP_FLAG_LOW_MEMORY)
+@pytest.mark.parametrize("n,n_eq,n_ineq,B,shared", [(100, 25, 275, 40, False), (13, 3, 20, 9, False), (60, 0, 128, 5, False),
+                                                    (80, 20, 300, 2100, True)])
+def test_low_memory_reads_K_from_the_table_bit_identical(n, n_eq, n_ineq, B, shared):
+    """low_memory=True drops the packed copy of K(rho) of the resident float32 kernel and loads K from the factor kernel's
+    row-major table (padding guarded per element): same K values, same kernel arithmetic -> bit-identical solves, on every
+    resident tile, through update(Hx, Ax), and on the straggler hand-off of an MFMA batch (shared matrices, B >= 2048)."""
+    if shared:
+        H, g0, A, l0, u0, _ = utils.rand_qp(n, n_eq, n_ineq, seed=31, compute_sol=False, feasible=True)
+        upd = [utils.update_qp(H, A, n_eq, n_ineq, seed=32 + b, compute_sol=False, feasible=True) for b in range(64)]
+        idx = np.arange(B) % 64
+        g, l, u = (np.stack([x[k] for x in upd])[idx] for k in (1, 3, 4))
+        kern = "auto"
+    else:
+        H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=4100, feasible=True)
+        kern = "resident"
+    out = []
+    for low in (False, True):
+        m = _solver(H, g, A, l, u, precision=torch.float32, kernel=kern, low_memory=low)
+        assert m.kernel == ("mfma" if shared else "resident2")
+        r = m.solve()
+        first = (r.x.clone(), r.z.clone(), r.y.clone(), r.info.iter.clone(), list(r.info.status))
+        if not shared:
+            m.update(Hx=H * 1.01)
+            r = m.solve()
+        out.append(first + (r.x.clone(), r.info.iter.clone()))
+    a, b = out
+    for k in (0, 1, 2, 3, 5, 6):
+        assert torch.equal(a[k], b[k]), k
+    assert a[4] == b[4] and all(s == "solved" for s in a[4])

@@ -499,7 +499,7 @@ def test_cabi_error_paths_on_device():
     dev = _dev()
     s = _cabi.CSettings()
     lib.rqp_default_settings(ctypes.byref(s))
-    d = _cabi.Dims(n=4, m=6, batch=2, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, reserved=0)
+    d = _cabi.Dims(n=4, m=6, batch=2, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, flags=0)
     h = ctypes.c_void_p()
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(d), ctypes.byref(s), dev.index or 0) == 0
     try:

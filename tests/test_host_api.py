@@ -45,11 +45,11 @@ def test_host_only_entry_points():
     assert lib.rqp_default_settings(None) == -1
     # argument validation happens before any device call
     h = ctypes.c_void_p()
-    bad = _cabi.Dims(n=0, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, reserved=0)
+    bad = _cabi.Dims(n=0, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, flags=0)
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(bad), ctypes.byref(s), 0) == -1
-    bad = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=7, kernel=0, tile_dtype=0, reserved=0)
+    bad = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=7, kernel=0, tile_dtype=0, flags=0)
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(bad), ctypes.byref(s), 0) == -1
-    ok = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, reserved=0)
+    ok = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, flags=0)
     s.adaptive_rho_tolerance = 1.0
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(ok), ctypes.byref(s), 0) == -1
     assert lib.rqp_solve(None, None, None, None, None, None) == -1
@@ -64,7 +64,7 @@ def test_no_cpu_fallback():
     s = _cabi.CSettings()
     lib.rqp_default_settings(ctypes.byref(s))
     h = ctypes.c_void_p()
-    ok = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, reserved=0)
+    ok = _cabi.Dims(n=3, m=5, batch=1, shared_mats=0, dtype=0, kernel=0, tile_dtype=0, flags=0)
     assert lib.rqp_create(ctypes.byref(h), ctypes.byref(ok), ctypes.byref(s), 0) == -3   # RQP_ERR_HIP
     m = reluqpth.ReLU_QP()
     with pytest.raises(_cabi.RqpUnavailable):
