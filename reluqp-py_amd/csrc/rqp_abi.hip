@@ -325,7 +325,11 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, hipMalloc(&h->Ht, nm * n * h->ldn * e));
     HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));
     HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
-    HIP_TRY(h, hipMalloc(&h->K, nm * h->nrho * n * h->ldn * e));
+    {   // (+ a zeroed tail: the low-memory K load of the resident kernel reads up to one vector past a row's end)
+        const size_t kb = nm * h->nrho * n * h->ldn * e;
+        HIP_TRY(h, hipMalloc(&h->K, kb + 256));
+        HIP_TRY(h, hipMemsetAsync((char*)h->K + kb, 0, 256, s));
+    }
     HIP_TRY(h, hipMalloc(&h->g, B * n * e));
     HIP_TRY(h, hipMalloc(&h->l, B * m * e));
     HIP_TRY(h, hipMalloc(&h->u, B * m * e));

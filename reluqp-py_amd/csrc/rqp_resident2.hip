@@ -207,16 +207,29 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
             asm volatile("" : "+v"(lane_o), "+v"(wave_o));
             const int rr = lane_o >> 3, cc = lane_o & 7, wave = wave_o;
             const float* Kj = (const float*)a.K + ((a.sK == 0) ? (size_t)0 : (size_t)b * a.sK) + (size_t)j * n * a.ldn;
+            // Unguarded vector loads (4-byte aligned float4: the rows start at multiples of ldn floats, the lane's run at KC cc):
+            //  * columns >= n over-read into the next row (the table is allocated with a zeroed tail): those K entries meet
+            //    d = 0 exactly -- the A and H images are zero-padded, so the padding columns of d are 0 -- and K is finite;
+            //  * rows >= n (and the rows past the wave's CW) read row n - 1 instead and are multiplied by a 0 / 1 row mask.
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp) {
                 const int lr = KR * rr + 2 * kp, r = CW * wave + lr;
                 const bool ok0 = lr < CW && r < n, ok1 = lr + 1 < CW && r + 1 < n;
-                const float* row0 = Kj + (size_t)r * a.ldn + KC * cc;
+                const float* row0 = Kj + (size_t)(r < n ? r : n - 1) * a.ldn + KC * cc;
+                const float* row1 = Kj + (size_t)(r + 1 < n ? r + 1 : n - 1) * a.ldn + KC * cc;
+                float t0[KC], t1[KC];
 #pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const bool cin = KC * cc + c < n;
-                    kr[kp][c] = (f2){(ok0 && cin) ? row0[c] : 0.f, (ok1 && cin) ? row0[a.ldn + c] : 0.f};
+                for (int c = 0; c + 4 <= KC; c += 4) {
+                    const f4u u0 = *(const f4u*)(row0 + c), u1 = *(const f4u*)(row1 + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { t0[c + e] = u0[e]; t1[c + e] = u1[e]; }
                 }
+#pragma unroll
+                for (int c = KC - KC % 4; c < KC; ++c) { t0[c] = row0[c]; t1[c] = row1[c]; }
+                const f2 msk = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
+#pragma unroll
+                for (int c = 0; c < KC; ++c) kr[kp][c] = (f2){t0[c], t1[c]} * msk;
             }
         }
     };
