@@ -168,3 +168,22 @@ def test_update_sequences_float64_exact(n, n_eq, n_ineq, seed0, warm):
         for step, ((it, stat, x), (rit, rstat, rx)) in enumerate(zip(got, ref)):
             assert (it, stat) == (rit, rstat), (m.kernel, step, it, stat, rit, rstat)
             np.testing.assert_allclose(x, rx, rtol=0, atol=1e-8 * max(1.0, float(np.abs(rx).max())), err_msg="%s step %d" % (m.kernel, step))
+
+
+@pytest.mark.parametrize("n,n_eq,n_ineq,B,seed0,st", _cases())
+def test_low_memory_bit_identical_on_every_shape(n, n_eq, n_ineq, B, seed0, st):
+    """RQP_FLAG_LOW_MEMORY over-reads K rows past column n and masks rows past n (rqp_resident2.hip load_K): on every padding
+    edge of every resident tile the float32 solve must not change by a bit."""
+    import reluqp.reluqpth as reluqpth
+    if not _fits("resident", n, n_eq + n_ineq):
+        pytest.skip("no resident tile holds this shape")
+    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=seed0, feasible=True)
+    res = []
+    for low in (False, True):
+        m = reluqpth.ReLU_QP()
+        m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, kernel="resident", low_memory=low, **st)
+        assert m.kernel == "resident2"
+        r = m.solve()
+        res.append((r.x.clone(), r.z.clone(), r.y.clone(), r.info.iter.clone(), r.info.pri_res.clone(), r.info.dua_res.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
