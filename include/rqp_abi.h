@@ -40,7 +40,8 @@ enum rqp_dtype { RQP_F32 = 0, RQP_F64 = 1 };
  * config 5, SURVEY.md 7.3 "matrix tile fp16, x/z/lam and residual fp32").  K only
  * preconditions the residual correction dx = -K d: its rounding
  * changes the convergence rate, never the fixed point; H, A and every residual stay in
- * dims.dtype.  RQP_TILE_F16 needs dims.dtype == RQP_F32.                               */
+ * dims.dtype.  RQP_TILE_F16 needs dims.dtype == RQP_F32.  The MFMA kernel (shared H, A)
+ * takes the same fp16-rounded K into its float32 operand image.                        */
 enum rqp_tile_dtype { RQP_TILE_SAME = 0, RQP_TILE_F16 = 1 };
 
 /* Solve-kernel request (rqp_dims.kernel).  AUTO = measured dispatch by size / batch /

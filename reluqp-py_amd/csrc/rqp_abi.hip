@@ -145,10 +145,12 @@ SetupArgs make_setup_args(const rqp_handle* h, const void* H, const void* g, con
 // Kernel selection (rqp_dims.kernel; AUTO = measured crossovers).  Pure function of the handle: no environment.
 int select_kernels(rqp_handle* h) {
     int req = h->dims.kernel;
-    if (h->dims.tile_dtype == RQP_TILE_F16) {     // the fp16 K tile lives in the register-resident kernel
-        if (req == RQP_KERNEL_AUTO && rqp_res2_fits(h)) req = RQP_KERNEL_RESIDENT;
-        if (req != RQP_KERNEL_RESIDENT)
-            return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320)");
+    if (h->dims.tile_dtype == RQP_TILE_F16) {     // the fp16 K tile lives in the register-resident kernel; the MFMA kernel takes
+                                                  // the same rounded K into its float32 operand image (k_pack_mfma)
+        const bool mfma_ok = rqp_mfma_fits(h) && rqp_res2_fits(h);
+        if (req == RQP_KERNEL_AUTO && rqp_res2_fits(h) && !(mfma_ok && h->B >= 2048 && (h->n > 56 || h->m > 128))) req = RQP_KERNEL_RESIDENT;
+        if (req != RQP_KERNEL_RESIDENT && !((req == RQP_KERNEL_MFMA || req == RQP_KERNEL_AUTO) && mfma_ok))
+            return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320) or the MFMA kernel");
     }
     h->resident = h->resident64 = h->use_wave = h->use_mfma = false;
     h->kernel_name = "generic";

@@ -824,8 +824,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
 //   W3[w][tl][s][l] = A[16 (MBW w + tl) + (l & 15)][4 s + (l >> 4)]
 //   K[j][w][s][t][l] = K_j[16 t + (l & 15)][4 (KS2 w + s) + (l >> 4)]
 template <class C>
+// Kscale != NULL (rqp_dims.tile_dtype = RQP_TILE_F16): K_j enters the image rounded to the fp16 tile of the resident kernel --
+// (half)(K / scale_j) * scale_j with the power-of-two scale k_pack_res2 chose -- so the MFMA phase and the resident
+// continuation of a solve see the SAME K.  The MFMA operands are float32 registers either way; K only preconditions.
 __global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __restrict__ A, const float* __restrict__ Ht,
-                            const float* __restrict__ K, float* __restrict__ img) {
+                            const float* __restrict__ K, float* __restrict__ img, const float* __restrict__ Kscale) {
     constexpr int NB = C::NB, MBW = C::MBW, MP = C::MP, KS1 = C::KS1, KS2 = C::KS2, KS3 = C::KS3, NW = C::NW;
     const size_t total = C::W1_ELEMS + C::W3_ELEMS + (size_t)nrho * C::KJ_ELEMS;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -847,6 +850,10 @@ __global__ void k_pack_mfma(int n, int m, int ldn, int nrho, const float* __rest
             const int j = (int)(o / C::KJ_ELEMS), q = (int)((o % C::KJ_ELEMS) >> 6), t = q % NB, s = (q / NB) % KS2, w = q / (NB * KS2);
             const int r = 16 * t + i16, c = 4 * (KS2 * w + s) + kq;
             if (r < n && c < n) v = K[((size_t)j * n + r) * ldn + c];
+            if (Kscale) {
+                const float sc = Kscale[j];
+                v = (float)(_Float16)(v * (1.f / sc)) * sc;               // (sc is a power of two: both scalings are exact)
+            }
         }
         img[idx] = v;
     }
@@ -887,7 +894,8 @@ size_t rqp_mfma_img_elems(const rqp_handle* h) {
 }
 
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
-    k_pack_mfma<CfgM55><<<256, 256, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht, (const float*)h->K, h->W1img);
+    k_pack_mfma<CfgM55><<<256, 256, 0, s>>>(h->n, h->m, h->ldn, h->nrho, (const float*)h->A, (const float*)h->Ht, (const float*)h->K, h->W1img,
+                                        h->dims.tile_dtype == RQP_TILE_F16 ? h->Kscale : nullptr);
     int* meta = (int*)(h->W1img + CfgM55::W1_ELEMS + CfgM55::W3_ELEMS + (size_t)h->nrho * CfgM55::KJ_ELEMS);
     k_meta_mfma<CfgM55><<<1, 64, 0, s>>>(h->W1img, meta);
     return hipGetLastError();

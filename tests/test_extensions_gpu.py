@@ -249,18 +249,18 @@ def test_resident_big_tile_fixed_k_and_residuals_vs_oracle():
 
 
 # ------------------------------------------------------------------- fp16 K tile (BASELINE config 5)
-@pytest.mark.parametrize("shape", ["c3", "dense"])
+@pytest.mark.parametrize("shape", ["c3", "dense", "c3_mfma"])
 def test_fp16_tile_same_exits_as_float32(shape):
     """iterate_dtype=float16 (C-ABI rqp_dims.tile_dtype = RQP_TILE_F16): K(rho) stored as fp16 in the resident kernel.
     K only preconditions the residual correction, so the fixed point is the float32 one: every instance solved, the
     same iteration counts on >= 85 % of the batch (stated tolerance; fp16 rounding of K shifts marginal checks), x within
     eps_abs-level of the float32-tile run where the exits agree, KKT residuals re-derived in float64 under the thresholds."""
     import reluqp.reluqpth as reluqpth
-    if shape == "c3":
+    if shape in ("c3", "c3_mfma"):
         from reluqp import mpc
         Ad, Bd = mpc.random_plant(12, 4, seed=0)
         ctl = mpc.LinearMPC(Ad, Bd, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
-        x0 = np.random.RandomState(3).randn(96, 12)
+        x0 = np.random.RandomState(3).randn(96 if shape == "c3" else 2064, 12)
         g, l, u = ctl.qp_vectors(x0)
         H, A = ctl.H, ctl.A
     else:
@@ -268,8 +268,9 @@ def test_fp16_tile_same_exits_as_float32(shape):
     out = {}
     for tile in (None, torch.float16):
         m = reluqpth.ReLU_QP()
-        m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, eps_abs=1e-3, iterate_dtype=tile, kernel="resident")
-        assert m.kernel == "resident2"
+        m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, eps_abs=1e-3, iterate_dtype=tile,
+                kernel="auto" if shape == "c3_mfma" else "resident")
+        assert m.kernel == ("mfma" if shape == "c3_mfma" else "resident2")      # (the MFMA image takes the same rounded K)
         out[tile] = m.solve()
     r32, r16 = out[None], out[torch.float16]
     assert all(s == "solved" for s in r16.info.status) and all(s == "solved" for s in r32.info.status)
