@@ -668,3 +668,24 @@ def test_low_memory_reads_K_from_the_table_bit_identical(n, n_eq, n_ineq, B, sha
     for k in (0, 1, 2, 3, 5, 6):
         assert torch.equal(a[k], b[k]), k
     assert a[4] == b[4] and all(s == "solved" for s in a[4])
+
+
+# ------------------------------------------------------------------- the C ABI from a host program without Python / torch
+def test_c_abi_example_program(tmp_path):
+    """reluqp-py_amd/examples/c_abi_solve.cpp: hipMalloc'd buffers, rqp_create / rqp_setup / rqp_solve / rqp_destroy through
+    include/rqp_abi.h only -- built with hipcc against librqp_hip.so and run as its own process (it checks its three
+    closed-form minimisers itself and prints `ok`)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "c_abi_solve")
+    lib = os.path.join(root, "reluqp-py_amd", "reluqp", "lib")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "reluqp-py_amd", "examples", "c_abi_solve.cpp"), "-L", lib, "-lrqp_hip",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert out.strip().endswith("ok") and out.count("status=0") == 3, out
