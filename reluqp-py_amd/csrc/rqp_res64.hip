@@ -83,6 +83,10 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int rr = lane >> 2, cc = lane & 3;
+    // Waves w and w + 4 share a SIMD; VALU issue is arbitrated by priority, then age, so the second-dispatched half loses every
+    // segment (RQP_DIAG: A' nu + H x 2 624 vs 2 263 cycles) and the first half waits for it at each barrier.  One static
+    // priority step for that half evens the pair out (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     const double* A = (const double*)a.A + (size_t)b * a.sA;
     const double* Ht = (const double*)a.Ht + (size_t)b * a.sH;
     const double* Kb = (const double*)a.K + (size_t)b * a.sK;
