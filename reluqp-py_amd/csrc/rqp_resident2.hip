@@ -335,20 +335,48 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         };
         // reduce-scatter over the 32 row groups of the wave (lane bits 5,4 by swaps; 3,2,1 by DPP); columns are
         // produced in the order the first swap level consumes them (0, H1, 1, H1+1, ...), so few sums are live
+        // The two columns of a swap pair are summed TOGETHER, their FMAs alternating: each column is one dependent chain, and
+        // two dependent v_pk_fma_f32 back to back cost a hazard s_nop (4 issue cycles) -- the H tail of a lone column had two
         float s1[H1];
+        auto colsum2 = [&](int c0, int c1, const float4& h0, const float4& h1, float& a0, float& a1) __attribute__((always_inline)) {
+            f2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
+            if constexpr (USE_A) {
+#pragma unroll
+                for (int rp = 0; rp < RP; ++rp) {
+                    t0 = __builtin_elementwise_fma(ar[rp][c0], wr[rp], t0);
+                    t1 = __builtin_elementwise_fma(ar[rp][c1], wr[rp], t1);
+                }
+            }
+            if constexpr (USE_H) {
+                t0 = __builtin_elementwise_fma((f2){h0.x, h0.y}, wx[0], t0);
+                t1 = __builtin_elementwise_fma((f2){h1.x, h1.y}, wx[0], t1);
+                t0 = __builtin_elementwise_fma((f2){h0.z, h0.w}, wx[1], t0);
+                t1 = __builtin_elementwise_fma((f2){h1.z, h1.w}, wx[1], t1);
+            }
+            a0 = t0.x + t0.y;
+            a1 = t1.x + t1.y;
+        };
         float4 hcur = {0.f, 0.f, 0.f, 0.f}, hnext = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (USE_H) hcur = hload(0);
+        if constexpr (USE_H) {
+            hcur = hload(0);
+            if (H1 < CQ) hnext = hload(H1);
+        }
 #pragma unroll
         for (int i = 0; i < H1; ++i) {
             const bool pair = (i + H1 < CQ);
-            if constexpr (USE_H) hnext = pair ? hload(i + H1) : ((i + 1 < H1) ? hload(i + 1) : hcur);
-            const float a0 = colsum(i, hcur);
             if (pair) {
-                if constexpr (USE_H) hcur = (i + 1 < H1) ? hload(i + 1) : hnext;
-                const float a1 = colsum(i + H1, hnext);
+                float4 hc2 = hcur, hn2 = hnext;                          // next pair's H rows: requested before this pair's FMAs
+                if constexpr (USE_H) {
+                    if (i + 1 < H1) hc2 = hload(i + 1);
+                    if (i + 1 + H1 < CQ) hn2 = hload(i + 1 + H1);
+                }
+                float a0, a1;
+                colsum2(i, i + H1, hcur, hnext, a0, a1);
                 s1[i] = swsum32(a0, a1);
+                hcur = hc2;
+                hnext = hn2;
             } else {
-                if constexpr (USE_H) hcur = hnext;
+                const float a0 = colsum(i, hcur);
                 s1[i] = swsum32(a0, a0);
             }
         }
