@@ -156,13 +156,16 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         double s[RL];
 #pragma unroll
         for (int r = 0; r < RL; ++r) s[r] = 0.0;
-#pragma unroll
+        double vc[CW];                                                // all 13 broadcasts first (scalar registers): a v_readlane result
+#pragma unroll                                                        // used by the very next VALU instruction costs a hazard s_nop
         for (int c = 0; c < CW; ++c) {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane(vlo, 4 * c), hi = (unsigned)__builtin_amdgcn_readlane(vhi, 4 * c);
-            const double vc = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-#pragma unroll
-            for (int r = 0; r < RL; ++r) s[r] = fma(ar[r][c], vc, s[r]);
+            vc[c] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         }
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+            for (int r = 0; r < RL; ++r) s[r] = fma(ar[r][c], vc[c], s[r]);
 #pragma unroll
         for (int r = 0; r < RL; ++r) part[(RL * lane + r) * R64_PS + wave] = s[r];
     };

@@ -281,10 +281,11 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 
     // ---- products ------------------------------------------------------------------------------------
     // wave partial of A v over the wave's CW columns -> part[wave][row]   (v: this wave's CW entries)
-    auto prod_A = [&](const float* v) {
-        float vc[CQ];
+    auto load_vc = [&](const float* v, float (&vc)[CQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < CQ; ++c) vc[c] = v[SW * wave + CQ * q + c];
+    };
+    auto prod_A = [&](const float (&vc)[CQ]) __attribute__((always_inline)) {
         f2 acc[RP];
 #pragma unroll
         for (int rp = 0; rp < RP; ++rp) {
@@ -425,14 +426,13 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
             s[2 * kp] = t.x;
             s[2 * kp + 1] = t.y;
         }
+        // (level by level over all rows: a DPP read of a register the previous VALU instruction wrote costs two wait states)
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            float t = s[r];
-            t += dpp2<0xB1>(t);
-            t += dpp2<0x4E>(t);
-            t += dpp2<0x141>(t);      // row_half_mirror
-            s[r] = t;
-        }
+        for (int r = 0; r < KR; ++r) s[r] += dpp2<0xB1>(s[r]);
+#pragma unroll
+        for (int r = 0; r < KR; ++r) s[r] += dpp2<0x4E>(s[r]);
+#pragma unroll
+        for (int r = 0; r < KR; ++r) s[r] += dpp2<0x141>(s[r]);         // row_half_mirror
     };
     // rows owned by this thread: tid (all waves) and tid + 256 (wave 0 only)
     // do_a: A x += sum of the 4 wave partials ; z = clamp(A x + lam/rho)      (completes state k)
@@ -508,6 +508,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         if (tid < M) row_body(std::integral_constant<int, 1>{}, init, do_a, do_b);
     };
 
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): A, K and the vectors have landed (see the rho move)
     unsigned long long t_last = 0, t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int seg) {
         if constexpr (DIAG) {
@@ -528,7 +529,11 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     const int kmax = (a.mode == 2) ? 0 : a.max_iter;
 
     // ---- A x and H x of the incoming state
-    prod_A(xin);
+    {
+        float vc0[CQ];
+        load_vc(xin, vc0);
+        prod_A(vc0);
+    }
     __syncthreads();
     row_pass(true, false, kmax > k0);
 
@@ -614,7 +619,18 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 #pragma unroll
             for (int hlf = 0; hlf < KR / 2; ++hlf) xold[hlf] = xp[hlf];
             prod_K(dvec, s);                                           // K d
+            // dx goes to LDS first and the A dx operands are requested right behind it: the float64 x update below runs
+            // while that same-wave LDS hop is in flight (LDS operations of a wave execute in order: behind the x stores the
+            // reads would wait for them too)
             if (cc == 0) {                 // this lane owns slots j..j+3 (rows >= CW of the group: zero rows of K, padding slots)
+#pragma unroll
+                for (int hlf = 0; hlf < KR / 2; ++hlf) ((f2*)(dxv + j))[hlf] = (f2){-s[2 * hlf], -s[2 * hlf + 1]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // dx of this wave's columns: same-wave LDS hop
+            __builtin_amdgcn_wave_barrier();
+            float vc[CQ];
+            load_vc(dxv, vc);
+            if (cc == 0) {
                 f2* xn2 = (f2*)(xnat + CW * wave + KR * rr);                   // natural order: real columns only
 #pragma unroll
                 for (int hlf = 0; hlf < KR / 2; ++hlf) {
@@ -624,16 +640,13 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
                     xa.y += (double)dx.y;
                     xp[hlf] = xa;
                     const f2 xf = {(float)xa.x, (float)xa.y};
-                    ((f2*)(dxv + j))[hlf] = dx;
                     ((f2*)(xin + j))[hlf] = xf;
                     if (KR * rr + 2 * hlf + 1 < CW) xn2[hlf] = xf;
                 }
             }
+            stamp(3);
+            prod_A(vc);                                                // partial A dx
         }
-        stamp(3);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // dx of this wave's columns: same-wave LDS hop
-        __builtin_amdgcn_wave_barrier();
-        prod_A(dxv);                                                   // partial A dx
         stamp(4);
         __syncthreads();                                               // B2: partials and x visible
         stamp(5);
@@ -672,6 +685,9 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
             if (ri != ri_before) {                                     // adaptive-rho "re-factor": table lookup
                 load_K(ri);
                 set_rho_rows(ri);
+                // wait for the K loads HERE: left pending, the compiler guards every first use of a K register in the solve
+                // loop with its own s_waitcnt vmcnt(N) -- 14 wait instructions per iteration that almost never wait
+                __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
             }
             if (k < kmax) row_pass(false, false, true);
             stamp(8);
