@@ -27,6 +27,18 @@ __global__ void k(float* out, unsigned long long* cyc, float seed) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[(i + 8) & 15]), 0xB1, 0xF, 0xF, true));
+        } else if (MODE == 4) {                 // v_permlane32_swap with its two wait states (8 independent pairs)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
+        } else if (MODE == 5) {                 // the swap alone (operands not written by the previous instruction)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
+        } else if (MODE == 6) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
+        } else if (MODE == 7) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("s_nop 1");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -51,6 +63,7 @@ void run(const char* name, int ninst, int threads) {
 int main() {
     for (int t : {256, 512, 1024}) {
         run<0>("v_fma_f32", 16, t); run<1>("v_pk_fma_f32", 16, t); run<2>("v_fma_f64", 8, t); run<3>("v_add_f32_dpp", 16, t);
+        run<4>("nop1+swap32", 8, t); run<5>("permlane32_swap", 8, t); run<6>("permlane16_swap", 8, t); run<7>("s_nop 1", 16, t);
     }
     return 0;
 }
