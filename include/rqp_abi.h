@@ -173,9 +173,12 @@ int rqp_update_mats(rqp_handle* h, const void* H, const void* A, void* stream);
 int rqp_update_affine(rqp_handle* h, const void* p, int32_t np, const void* Gg, const void* Glu,
                       const void* l0, const void* u0, void* stream);
 
-/* ReLU_QP.update_settings (reluqpth.py:185-199): only max_iter, eps_abs and
- * check_interval may change after setup; a difference in any other field returns
- * RQP_ERR_ARG (the reference raises ValueError).                                  */
+/* ReLU_QP.update_settings (reluqpth.py:185-199, whose whitelist is max_iter, eps_abs, verbose,
+ * check_interval).  Changeable after setup: max_iter, eps_abs, check_interval, warm_starting and
+ * the extension fields eps_rel, check_infeasibility, eps_prim_inf, eps_dual_inf.  A difference in
+ * any other field (rho, rho_min, rho_max, sigma, adaptive_rho, adaptive_rho_tolerance, eq_tol,
+ * scaling -- they shape the K(rho) ladder built at setup) returns RQP_ERR_ARG (the reference
+ * raises ValueError).                                                                          */
 int rqp_update_settings(rqp_handle* h, const rqp_settings* settings);
 
 /* ReLU_QP.warm_start (reluqpth.py:251-276) with Q6 fixed (values are written into
@@ -218,6 +221,19 @@ int rqp_get_rhos(const rqp_handle* h, double* rhos, int32_t cap, int32_t* count)
 /* K_j of instance b (ReLU_Layer.kkt_rhs_invs[j], reluqpth.py:56) -> out [n][n]
  * in dims.dtype (device pointer).  For parity tests.                              */
 int rqp_get_K(rqp_handle* h, int32_t b, int32_t j, void* out, void* stream);
+
+/* Dispatch order of the per-instance kernels.  After every solve the library ranks the instances by
+ * the iteration count they just needed and issues the next launch longest-first (pure scheduling:
+ * results never depend on it; it pays when consecutive solves resemble each other -- closed loops,
+ * parameter sweeps).  mode 1 = on (default), 0 = off: every launch in grid order, nothing recorded
+ * (a handle then behaves at every solve like a fresh handle on a fresh batch), 2 = forget the
+ * recorded order now and stay on.  No reference counterpart (one QP per object there).            */
+int rqp_dispatch_history(rqp_handle* h, int32_t mode);
+
+/* Inspection hook for the tests: the workgroup -> instance permutation the NEXT launch would use and the
+ * iteration counts it was ranked by (device arrays [batch] of int32, NULL to skip).  *valid (host)
+ * receives 1 when a recorded order exists, else 0 (then nothing is copied).                       */
+int rqp_get_dispatch(rqp_handle* h, int32_t* order, int32_t* last_iter, int32_t* valid, void* stream);
 
 /* Which solve kernel the handle dispatches to ("generic", "resident", ...).       */
 const char* rqp_kernel_name(const rqp_handle* h);

@@ -500,7 +500,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     a.out_x = x; a.out_z = z; a.out_lam = lam;
     if (info) a.info = *info;
     if (a.info.trace && a.info.trace_cap < 1) return fail_arg(h, "rqp_solve: trace without capacity");
-    if (h->order_d) {
+    if (h->order_d && h->use_history) {
         a.order = h->order_valid ? h->order_d : nullptr;
         a.last_iter = h->last_iter_d;
     }
@@ -533,7 +533,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.keep_state = 0;
         HIP_TRY(h, rqp_launch_solve_generic(h, c, (hipStream_t)stream));
     }
-    if (h->order_d) {                               // rank the instances by what they just needed: next launch goes longest-first
+    if (h->order_d && h->use_history) {             // rank the instances by what they just needed: next launch goes longest-first
         HIP_TRY(h, rqp_launch_order_lpt(h, (hipStream_t)stream));
         h->order_valid = true;
     }
@@ -592,6 +592,25 @@ int rqp_get_K(rqp_handle* h, int32_t b, int32_t j, void* out, void* stream) {
     if (b < 0 || b >= h->B || j < 0 || j >= h->nrho) return fail_arg(h, "rqp_get_K: index out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, rqp_launch_get_K(h, b, j, out, (hipStream_t)stream));
+    return RQP_OK;
+}
+
+int rqp_dispatch_history(rqp_handle* h, int32_t mode) {
+    if (!h || mode < 0 || mode > 2) return RQP_ERR_ARG;
+    h->order_valid = false;
+    if (mode != 2) h->use_history = mode == 1;
+    return RQP_OK;
+}
+
+int rqp_get_dispatch(rqp_handle* h, int32_t* order, int32_t* last_iter, int32_t* valid, void* stream) {
+    if (!h || !valid) return RQP_ERR_ARG;
+    if (!h->is_setup) return RQP_ERR_STATE;
+    *valid = (h->order_d && h->order_valid) ? 1 : 0;
+    if (!*valid) return RQP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nb = (size_t)h->B * sizeof(int32_t);
+    if (order) HIP_TRY(h, hipMemcpyAsync(order, h->order_d, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (last_iter) HIP_TRY(h, hipMemcpyAsync(last_iter, h->last_iter_d, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return RQP_OK;
 }
 

@@ -65,6 +65,7 @@ struct rqp_handle {
     int32_t* order_d = nullptr;   // [B] instance of workgroup i
     int32_t* last_iter_d = nullptr;
     bool order_valid = false;
+    bool use_history = true;      // rqp_dispatch_history
     int ncu = 0;                  // compute units of `device` (cached at rqp_create)
     int debug = 0;                // bit 0: RQP_DEBUG (occupancy print at setup), bit 1: RQP_DIAG (s_memtime build); read ONCE
                                   // at rqp_create -- diagnostics only, kernel selection never depends on the environment

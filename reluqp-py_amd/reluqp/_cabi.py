@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_mats", "rqp_update_affine",
     "rqp_update_settings",
     "rqp_warm_start", "rqp_clear_primal_dual", "rqp_solve", "rqp_iterate", "rqp_compute_residuals",
-    "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
+    "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_dispatch_history", "rqp_get_dispatch", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
     "rqp_last_error", "rqp_version",
 )
 
@@ -98,6 +98,8 @@ def load():
         "rqp_get_state": (ctypes.c_int, [H, vp, vp, vp, vp, vp]),
         "rqp_get_rhos": (ctypes.c_int, [H, ctypes.POINTER(dbl), i32, ctypes.POINTER(i32)]),
         "rqp_get_K": (ctypes.c_int, [H, i32, i32, vp, vp]),
+        "rqp_dispatch_history": (ctypes.c_int, [H, i32]),
+        "rqp_get_dispatch": (ctypes.c_int, [H, vp, vp, ctypes.POINTER(i32), vp]),
         "rqp_kernel_name": (ctypes.c_char_p, [H]),
         "rqp_destroy": (ctypes.c_int, [H]),
         "rqp_strerror": (ctypes.c_char_p, [ctypes.c_int]),

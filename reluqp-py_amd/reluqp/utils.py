@@ -91,12 +91,54 @@ def update_qp(H, A, n_eq, n_ineq, seed=1, compute_sol=True, feasible=False):
     return H, g, Afull, l, u, x_sol
 
 
-def rand_qp_batch(batch, nx, n_eq, n_ineq, seed0=0, feasible=True, dtype=np.float64):
+def _shared_empty(shape, dtype):
+    """numpy array on an anonymous shared mapping: children forked afterwards write into the parent's memory."""
+    import mmap
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    buf = mmap.mmap(-1, max(nbytes, 1))
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def _fill_chunk(out, a, b, nx, n_eq, n_ineq, seed0, feasible):
+    try:                                      # one BLAS thread per child: the processes are the parallelism
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except ImportError:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        for i in range(a, b):
+            Hi, gi, Ai, li, ui, xi = rand_qp(nx, n_eq, n_ineq, seed=seed0 + i, compute_sol=feasible, feasible=feasible)
+            out[0][i], out[1][i], out[2][i], out[3][i], out[4][i] = Hi, gi, Ai, li, ui
+            if xi is not None:
+                out[5][i] = xi
+
+
+def rand_qp_batch(batch, nx, n_eq, n_ineq, seed0=0, feasible=True, dtype=np.float64, workers=0):
     """Stack ``batch`` independent instances; instance i uses seed ``seed0 + i``.
 
     Returns ``H[B,n,n], g[B,n], A[B,m,n], l[B,m], u[B,m], x_sol[B,n]`` (x_sol is
-    the planted optimum in feasible mode, NaN otherwise).
+    the planted optimum in feasible mode, NaN otherwise).  ``workers > 1`` draws
+    contiguous chunks in that many forked child processes writing into shared
+    memory (same instances, same seeds; call it before the process initialises a GPU).
     """
+    m = n_eq + n_ineq
+    if workers and workers > 1 and batch >= 4 * workers:
+        import multiprocessing as mp
+        shapes = ((batch, nx, nx), (batch, nx), (batch, m, nx), (batch, m), (batch, m), (batch, nx))
+        out = [_shared_empty(sh, dtype) for sh in shapes]
+        out[5][:] = np.nan
+        edges = np.linspace(0, batch, workers + 1).astype(int)
+        ctx = mp.get_context("fork")
+        ps = [ctx.Process(target=_fill_chunk, args=(out, int(a), int(b), nx, n_eq, n_ineq, seed0, feasible))
+              for a, b in zip(edges[:-1], edges[1:])]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join()
+            if p.exitcode != 0:
+                raise RuntimeError("rand_qp_batch worker failed (exit code %s)" % p.exitcode)
+        return tuple(out)
     m = n_eq + n_ineq
     H = np.empty((batch, nx, nx), dtype)
     g = np.empty((batch, nx), dtype)
