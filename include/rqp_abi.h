@@ -89,9 +89,17 @@ typedef struct rqp_dims {
 
 /* rqp_dims.flags */
 enum {
-    RQP_FLAG_LOW_MEMORY = 1   /* resident float32 kernel: read K(rho) straight from the row-major table instead of a packed
-                                 lane-linear copy -- 43 % less workspace (3.9 of 9 GB at batch 4096, n = 100, m = 300) and
-                                 12 % less setup time for 1 % more solve time; results are bit-identical            */
+    RQP_FLAG_LOW_MEMORY = 1,  /* resident float32 kernel: read K(rho) straight from the row-major table instead of a packed
+                                 lane-linear copy: less workspace and setup time for ~1 % more solve time; results are
+                                 bit-identical                                                                      */
+    RQP_FLAG_FULL_LADDER = 2  /* build K(rho) for EVERY entry of the rho ladder of every matrix, as the reference does
+                                 (reluqpth.py:52-78).  Default for batches of >= 32 per-instance matrices on the resident
+                                 float32 / streaming kernels: a WINDOW of 5 entries around each instance's index
+                                 (rho_ind0 - 1 .. rho_ind0 + 3 at setup; a solve visits 2-4 entries).  An instance whose
+                                 index leaves its window exits with its exact state, rqp_solve re-factors a window around
+                                 the new index and continues it -- results are bit-identical to the full ladder, setup and
+                                 workspace shrink by ~3x, and rqp_solve synchronises `stream` once per pass (it cannot be
+                                 captured into a HIP graph: use this flag there).                                    */
 };
 
 /* Settings of classes.py:32-65 that reach the device (same names, same defaults). */
@@ -234,6 +242,11 @@ int rqp_dispatch_history(rqp_handle* h, int32_t mode);
  * iteration counts it was ranked by (device arrays [batch] of int32, NULL to skip).  *valid (host)
  * receives 1 when a recorded order exists, else 0 (then nothing is copied).                       */
 int rqp_get_dispatch(rqp_handle* h, int32_t* order, int32_t* last_iter, int32_t* valid, void* stream);
+
+/* K(rho) slots per matrix of this handle: *slots = the ladder length (whole ladder) or the window size
+ * (see RQP_FLAG_FULL_LADDER); wbase (device int32 [batch], NULL to skip; windowed handles only) receives the
+ * ladder index of slot 0 of every instance's window.  For tests.                                        */
+int rqp_get_window(rqp_handle* h, int32_t* slots, int32_t* wbase, void* stream);
 
 /* Which solve kernel the handle dispatches to ("generic", "resident", ...).       */
 const char* rqp_kernel_name(const rqp_handle* h);

@@ -75,11 +75,21 @@ void free_ws(rqp_handle* h) {
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
                      (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
                      (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d, (void**)&h->cont_iter_d, (void**)&h->cont_rho_d,
-                     (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc};
+                     (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc, (void**)&h->wbase_d, (void**)&h->ax_d, (void**)&h->cstat_d,
+                     (void**)&h->ncont_d};
+    // hipFree is one of the calls that invalidate a stream capture in progress (global / thread-local capture modes).  A handle
+    // may be destroyed while this thread captures something else (a Python finaliser, an explicit `del`): free under the
+    // relaxed mode, which exists for exactly this.
+    hipStreamCaptureMode cmode = hipStreamCaptureModeRelaxed;
+    const bool swapped = hipThreadExchangeStreamCaptureMode(&cmode) == hipSuccess;
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (h->ncont_h) (void)hipHostFree(h->ncont_h);
+    if (swapped) (void)hipThreadExchangeStreamCaptureMode(&cmode);
+    h->ncont_h = nullptr;
+    h->windowed = false;
     h->is_setup = false;
     h->order_valid = false;
     h->resident = false;
@@ -120,7 +130,16 @@ SolveArgs make_solve_args(const rqp_handle* h) {
     a.sH = sh ? 0 : (size_t)h->n * h->ldn;
     a.sA = sh ? 0 : (size_t)h->m * h->ldn;
     a.sAt = sh ? 0 : (size_t)h->n * h->ldm;
-    a.sK = sh ? 0 : (size_t)h->nrho * h->n * h->ldn;
+    a.sK = sh ? 0 : (size_t)h->kwin * h->n * h->ldn;
+    a.kwin = h->kwin;
+    if (h->windowed) {
+        a.wbase = h->wbase_d;
+        a.ax = h->ax_d;
+        a.cstat = h->cstat_d;
+        a.ncont = h->ncont_d;
+        a.cont_iter = h->cont_iter_d;
+        a.cont_rho = h->cont_rho_d;
+    }
     a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
     a.rhos = h->rhos_d;
     a.x = h->x; a.z = h->z; a.lam = h->lam; a.rho_ind = h->rho_ind;
@@ -139,6 +158,8 @@ SetupArgs make_setup_args(const rqp_handle* h, const void* H, const void* g, con
     a.G = h->G;
     a.rhos = h->rhos_d;
     a.fscratch = h->fscratch;
+    a.kwin = h->kwin;
+    a.wbase = h->windowed ? h->wbase_d : nullptr;
     return a;
 }
 
@@ -194,6 +215,13 @@ int select_kernels(rqp_handle* h) {
     // RQP_FLAG_LOW_MEMORY: the float32 resident kernel reads K from the row-major table (no effect on the other kernels, which
     // have no packed copy of it; the fp16 tile IS the smaller copy)
     h->k_direct = (h->dims.flags & RQP_FLAG_LOW_MEMORY) && h->resident && h->dims.tile_dtype != RQP_TILE_F16;
+    // rho-ladder window (rqp_common.h): batches of per-instance matrices whose solve kernel runs the exit-and-continue protocol
+    // (resident float32 tile, streaming kernel).  Not with check_infeasibility (its certificate pass reads K at the final index)
+    // and not on request (RQP_FLAG_FULL_LADDER: rqp_solve then never synchronises the host, e.g. for graph capture).
+    h->kwin = h->nrho;
+    h->windowed = !h->dims.shared_mats && h->nmat >= 32 && h->nrho > RQP_WINDOW && !(h->dims.flags & RQP_FLAG_FULL_LADDER) &&
+                  !h->st.check_infeasibility && !h->use_mfma && !h->use_wave && !h->resident64;
+    if (h->windowed) h->kwin = RQP_WINDOW;
     if (h->use_mfma) h->kernel_name = "mfma";
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
@@ -218,7 +246,7 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
             HIP_TRY(h, rqp_prepare_res2(h));
         }
-        HIP_TRY(h, rqp_launch_pack_res2(h, s));
+        HIP_TRY(h, rqp_launch_pack_res2(h, nullptr, s));
     }
     if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
@@ -328,7 +356,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));
     HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
     {   // (+ a zeroed tail: the low-memory K load of the resident kernel reads up to one vector past a row's end)
-        const size_t kb = nm * h->nrho * n * h->ldn * e;
+        const size_t kb = nm * h->kwin * n * h->ldn * e;
         HIP_TRY(h, hipMalloc(&h->K, kb + 256));
         HIP_TRY(h, hipMemsetAsync((char*)h->K + kb, 0, 256, s));
     }
@@ -345,13 +373,25 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, hipMemcpyAsync(h->rhos_d, h->rhos.data(), h->nrho * sizeof(double), hipMemcpyHostToDevice, s));
     const size_t lds_need = (n * n + 2 * n) * sizeof(double);
     if (lds_need > 160 * 1024 - 512) {   // factor scratch in global memory
-        h->fscratch_elems = nm * h->nrho * n * n;
+        h->fscratch_elems = nm * h->kwin * n * n;
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
     if (!h->use_mfma && h->B >= (h->resident64 ? 2 : 4) * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));
+    }
+    if (h->windowed) {
+        const int w0 = std::min(std::max(h->rho_ind0 - 1, 0), h->nrho - h->kwin);
+        HIP_TRY(h, hipMalloc((void**)&h->wbase_d, nm * sizeof(int32_t)));
+        HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->wbase_d, w0, nm, s));
+        HIP_TRY(h, hipMalloc((void**)&h->ax_d, B * m * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->cstat_d, B * sizeof(int32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->cstat_d, 0, B * sizeof(int32_t), s));
+        HIP_TRY(h, hipMalloc((void**)&h->ncont_d, sizeof(int32_t)));
+        HIP_TRY(h, hipHostMalloc((void**)&h->ncont_h, sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc((void**)&h->cont_iter_d, B * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void**)&h->cont_rho_d, B * sizeof(double)));
     }
     h->handoff_cols = 0;
     if (h->use_mfma && h->resident && (h->B + 15) / 16 <= h->ncu) {   // straggler hand-off (SolveArgs): one tile per CU at most
@@ -456,6 +496,9 @@ int rqp_update_settings(rqp_handle* h, const rqp_settings* s) {
                            "check_infeasibility, eps_prim_inf, eps_dual_inf may change");
     if (s->max_iter < 0 || s->check_interval < 1 || s->eps_abs < 0 || s->eps_rel < 0 || s->eps_prim_inf < 0 || s->eps_dual_inf < 0)
         return fail_arg(h, "rqp_update_settings: bad value");
+    if (h->windowed && s->check_infeasibility)
+        return fail_unsupported(h, "rqp_update_settings: check_infeasibility on a handle set up with a rho-ladder window; "
+                                   "pass check_infeasibility (or RQP_FLAG_FULL_LADDER) at setup");
     h->st.eps_rel = s->eps_rel;
     h->st.check_infeasibility = s->check_infeasibility;
     h->st.eps_prim_inf = s->eps_prim_inf;
@@ -491,10 +534,22 @@ int rqp_clear_primal_dual(rqp_handle* h, void* stream) {
     return RQP_OK;
 }
 
+// Windowed handles: re-centre and re-factor the windows of the marked instances (cstat = 1): k_rewindow -> K_j of the new
+// windows -> their kernel images.  Every kernel filters on cstat, so nothing here needs the host to know which instances.
+static int refactor_windows(rqp_handle* h, int all, hipStream_t s) {
+    HIP_TRY(h, rqp_launch_rewindow(h, all, s));
+    SetupArgs f = make_setup_args(h, nullptr, nullptr, nullptr, nullptr, nullptr);
+    f.only = h->cstat_d;
+    HIP_TRY(h, rqp_launch_factor(h, f, s));
+    if (h->resident) HIP_TRY(h, rqp_launch_pack_res2(h, h->cstat_d, s));
+    return RQP_OK;
+}
+
 int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, void* stream) {
     if (!h) return RQP_ERR_ARG;
     if (!h->is_setup) return RQP_ERR_STATE;
     HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
     SolveArgs a = make_solve_args(h);
     a.mode = 0;
     a.out_x = x; a.out_z = z; a.out_lam = lam;
@@ -503,6 +558,13 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     if (h->order_d && h->use_history) {
         a.order = h->order_valid ? h->order_d : nullptr;
         a.last_iter = h->last_iter_d;
+    }
+    if (h->windowed) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail_unsupported(h, "rqp_solve: a windowed handle synchronises the stream (rho-ladder window); set up with "
+                                       "RQP_FLAG_FULL_LADDER to capture solves into a HIP graph");
+        HIP_TRY(h, hipMemsetAsync(h->ncont_d, 0, sizeof(int32_t), s));
     }
     // Infeasibility certificates: the streaming kernel tests them at every check; the register-resident / MFMA kernels
     // keep their loops untouched and a mode-3 pass of the streaming kernel examines the instances that ran out of iterations.
@@ -515,7 +577,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         a.cont_rho = h->cont_rho_d;
         a.keep_state = 1;                           // the continue pass clears what warm_starting = 0 asks to clear
     }
-    HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_solve(h, a, s));
     if (handoff) {                                  // stragglers finish on the per-instance resident kernel
         SolveArgs c = a;
         c.cont = 1;
@@ -523,7 +585,23 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.keep_state = post_cert ? 1 : 0;
         c.order = nullptr;
         c.last_iter = nullptr;
-        HIP_TRY(h, rqp_launch_solve_res2(h, c, (hipStream_t)stream));
+        HIP_TRY(h, rqp_launch_solve_res2(h, c, s));
+    }
+    if (h->windowed) {
+        // instances whose rho index left their window stopped with their exact state: new windows, then they continue
+        // (at most one window move per `RQP_WINDOW / 2` index moves, i.e. per >= 2 checks of an instance)
+        for (;;) {
+            HIP_TRY(h, hipMemcpyAsync(h->ncont_h, h->ncont_d, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            if (*h->ncont_h <= 0) break;
+            const int rc = refactor_windows(h, 0, s);
+            if (rc != RQP_OK) return rc;
+            HIP_TRY(h, hipMemsetAsync(h->ncont_d, 0, sizeof(int32_t), s));
+            SolveArgs c = a;
+            c.cont = 2;
+            c.order = nullptr;
+            HIP_TRY(h, launch_solve(h, c, s));
+        }
     }
     if (post_cert) {
         SolveArgs c = a;
@@ -531,14 +609,14 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.order = nullptr;
         c.last_iter = nullptr;
         c.keep_state = 0;
-        HIP_TRY(h, rqp_launch_solve_generic(h, c, (hipStream_t)stream));
+        HIP_TRY(h, rqp_launch_solve_generic(h, c, s));
     }
     if (h->order_d && h->use_history) {             // rank the instances by what they just needed: next launch goes longest-first
-        HIP_TRY(h, rqp_launch_order_lpt(h, (hipStream_t)stream));
+        HIP_TRY(h, rqp_launch_order_lpt(h, s));
         h->order_valid = true;
     }
     if (h->st.scaling > 0)                          // x = D xb, z = zb / E, lam = E lamb / c, obj / c
-        HIP_TRY(h, rqp_launch_unscale_out(h, x, z, lam, a.info.obj_val, (hipStream_t)stream));
+        HIP_TRY(h, rqp_launch_unscale_out(h, x, z, lam, a.info.obj_val, s));
     return RQP_OK;
 }
 
@@ -549,6 +627,10 @@ int rqp_iterate(rqp_handle* h, int32_t k, void* stream) {
     SolveArgs a = make_solve_args(h);
     a.mode = 1;
     a.max_iter = k;
+    if (h->windowed) {                              // (test hook: no exit-and-continue here -- every window is centred first)
+        const int rc = refactor_windows(h, 1, (hipStream_t)stream);
+        if (rc != RQP_OK) return rc;
+    }
     HIP_TRY(h, launch_solve(h, a, (hipStream_t)stream));
     return RQP_OK;
 }
@@ -591,7 +673,46 @@ int rqp_get_K(rqp_handle* h, int32_t b, int32_t j, void* out, void* stream) {
     if (!h->is_setup) return RQP_ERR_STATE;
     if (b < 0 || b >= h->B || j < 0 || j >= h->nrho) return fail_arg(h, "rqp_get_K: index out of range");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, rqp_launch_get_K(h, b, j, out, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mat = h->dims.shared_mats ? 0 : (size_t)b, one = (size_t)h->n * h->ldn;
+    if (!h->windowed) {
+        HIP_TRY(h, rqp_launch_get_K(h, (const char*)h->K + (mat * h->nrho + j) * one * h->esz, out, s));
+        return RQP_OK;
+    }
+    // windowed handle: the entry may not exist in the table -- factor this one (matrix, rho) pair into a scratch matrix
+    void* tmp = nullptr;
+    double* fs = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, one * h->esz));
+    SetupArgs f = make_setup_args(h, nullptr, nullptr, nullptr, nullptr, nullptr);
+    f.nmat = 1;
+    f.kwin = 1;
+    f.wbase = nullptr;
+    f.only = nullptr;
+    f.Ht = (char*)h->Ht + mat * one * h->esz;
+    f.G = h->G + mat * (size_t)h->n * h->n;
+    f.K = tmp;
+    f.rhos = h->rhos_d + j;
+    int rc = RQP_OK;
+    if (h->fscratch) {                              // (large n: the factor kernel works in a global scratch slab)
+        if (hipMalloc((void**)&fs, (size_t)h->n * h->n * sizeof(double)) != hipSuccess) rc = RQP_ERR_OOM;
+        f.fscratch = fs;
+    }
+    if (rc == RQP_OK && rqp_launch_factor(h, f, s) != hipSuccess) rc = fail_hip(h, hipGetLastError(), "factor (rqp_get_K)");
+    if (rc == RQP_OK && rqp_launch_get_K(h, tmp, out, s) != hipSuccess) rc = fail_hip(h, hipGetLastError(), "k_get_K");
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (fs) (void)hipFree(fs);
+    return rc;
+}
+
+int rqp_get_window(rqp_handle* h, int32_t* slots, int32_t* wbase, void* stream) {
+    if (!h) return RQP_ERR_ARG;
+    if (!h->is_setup) return RQP_ERR_STATE;
+    if (slots) *slots = h->kwin;
+    if (wbase && h->windowed) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(wbase, h->wbase_d, (size_t)h->nmat * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     return RQP_OK;
 }
 

@@ -144,6 +144,31 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     const T* A = (const T*)a.A + (size_t)b * a.sA;
     const T* At = (const T*)a.At + (size_t)b * a.sAt;
     const T* Kb = (const T*)a.K + (size_t)b * a.sK;
+    const int wb = a.wbase ? a.wbase[(a.sK == 0) ? 0 : b] : 0;     // rho window: K slot s holds ladder index wb + s
+
+    // exit-and-continue of a windowed handle (SolveArgs.cont = 2, see rqp_resident2.hip): only the instances that left their
+    // window, resumed exactly where they stopped
+    int k0 = 0;
+    bool exact = false;
+    if (a.cont == 2) {
+        if (a.cstat[b] == 0) return;
+        const int ci = a.cont_iter[b];
+        if (ci >= 0) {
+            k0 = ci;
+            exact = true;
+        }
+    }
+    if (a.cstat && a.mode == 0) {
+        const int sl = a.rho_ind[b] - wb;
+        if (sl < 0 || sl >= a.kwin) {                              // incoming index outside the window: leave untouched
+            if (tid == 0) {
+                a.cstat[b] = 1;
+                if (!exact) a.cont_iter[b] = -1;
+                atomicAdd(a.ncont, 1);
+            }
+            return;
+        }
+    }
 
     if (a.mode == 3) {                       // certificate pass behind another solve kernel (rqp_solve): only the instances that
         const bool todo = a.info.status[b] == RQP_STATUS_MAX_ITER;      // spent their iterations are examined; the state the
@@ -171,16 +196,20 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
         cT[i] = ((const T*)a.c)[(size_t)b * m + i];
     }
     int ri = a.rho_ind[b];
-    T rho_est = (a.mode == 2) ? (T)a.rho_in : (T)a.rhos[ri];      // reluqpth.py:211
+    T rho_est = (a.mode == 2) ? (T)a.rho_in : (exact ? (T)a.cont_rho[b] : (T)a.rhos[ri]);      // reluqpth.py:211
     for (int i = tid; i < m; i += RQP_NT) rvT[i] = (T)a.rhos[ri] * cT[i];
     for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
     __syncthreads();
-    colmv<T>(At, ldm, n, m, vin, vm, part);                        // A x of the incoming state
-    for (int i = tid; i < m; i += RQP_NT) zts[i] = (double)vm[i];
+    if (!exact) {
+        colmv<T>(At, ldm, n, m, vin, vm, part);                    // A x of the incoming state
+        for (int i = tid; i < m; i += RQP_NT) zts[i] = (double)vm[i];
+    } else {                                                       // (an exact continuation brought it along)
+        for (int i = tid; i < m; i += RQP_NT) zts[i] = a.ax[(size_t)b * m + i];
+    }
     __syncthreads();
 
     bool hx_valid = false, converged = false;
-    int iters = 0;
+    int iters = k0;
     T pri = T(0), dua = T(0);
     const T tolT = (T)a.tol;
     const int kmax = (a.mode == 2) ? 0 : ((a.mode == 3) ? 1 : a.max_iter);
@@ -273,8 +302,9 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
         return est;
     };
 
-    for (int k = 1; k <= kmax; ++k) {
-        const T* Kj = Kb + (size_t)ri * n * ldn;
+    for (int k = k0 + 1; k <= kmax; ++k) {
+        const int slot = min(max(ri - wb, 0), a.kwin - 1);         // (in range in mode 0; modes 1 / 3 re-centre the windows first)
+        const T* Kj = Kb + (size_t)slot * n * ldn;
         if (!hx_valid) {
             for (int i = tid; i < n; i += RQP_NT) vin[i] = (T)xs[i];
             __syncthreads();
@@ -339,6 +369,23 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
                 cert = certificates();
                 if (cert) break;
             }
+            if (a.cstat && k < kmax && (ri < wb || ri >= wb + a.kwin)) {
+                // the new index has no K in this instance's window: leave with the exact state (see rqp_resident2.hip)
+                for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = xs[i];
+                for (int i = tid; i < m; i += RQP_NT) {
+                    a.z[(size_t)b * m + i] = zs[i];
+                    a.lam[(size_t)b * m + i] = ls[i];
+                    a.ax[(size_t)b * m + i] = zts[i];
+                }
+                if (tid == 0) {
+                    a.rho_ind[b] = ri;
+                    a.cont_iter[b] = k;
+                    a.cont_rho[b] = (double)rho_est;
+                    a.cstat[b] = 1;
+                    atomicAdd(a.ncont, 1);
+                }
+                return;
+            }
         }
     }
     if (a.mode == 3) {                                             // one iteration taken from the persisted state: its directions
@@ -389,6 +436,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     if (a.out_z) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_z)[(size_t)b * m + i] = (T)zs[i];
     if (a.out_lam) for (int i = tid; i < m; i += RQP_NT) ((T*)a.out_lam)[(size_t)b * m + i] = (T)ls[i];
     if (tid == 0) {
+        if (a.cstat) a.cstat[b] = 0;
         if (a.info.iter) a.info.iter[b] = (converged || cert) ? iters : a.max_iter;
         if (a.last_iter) a.last_iter[b] = (converged || cert) ? iters : a.max_iter;
         if (a.info.status)

@@ -11,6 +11,7 @@
 #include "rqp_abi.h"
 
 #define RQP_STATUS_CONTINUE (-2)   // internal: handed from the MFMA kernel to the per-instance kernel mid-solve (never returned)
+#define RQP_WINDOW 5        // K(rho) slots per matrix of a windowed handle (rho_ind0 - 1 .. rho_ind0 + 3 at setup)
 #define RQP_NT 256          // threads per workgroup of the generic kernels (4 wavefronts)
 #define RQP_WAVE 64         // CDNA wavefront
 
@@ -19,7 +20,8 @@
 //   Ht  [nmat][n][ldn]   T   H transposed (so that H x is a column-oriented product for any H)
 //   A   [nmat][m][ldn]   T   row-major, leading dim padded to a multiple of 16 B
 //   At  [nmat][n][ldm]   T   A transposed
-//   K   [nmat][nrho][n][ldn] T  K_j = (H + sigma I + A' diag(rho_j c) A)^-1, symmetric
+//   K   [nmat][kwin][n][ldn] T  K_j = (H + sigma I + A' diag(rho_j c) A)^-1, symmetric; slot s of matrix `mat` holds
+//                               ladder index wbase[mat] + s (kwin = nrho, wbase = 0: the whole ladder, as the reference builds it)
 //   G   [nmat][n][n]     double  A' diag(c) A   (setup only)
 //   g   [B][n], l,u,c [B][m]   T   (c_i = 1e3 on equality rows else 1)
 //   x   [B][n], z,lam [B][m]   double   ADMM state (float64 accumulators)
@@ -55,6 +57,18 @@ struct rqp_handle {
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
     int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
+    // rho-ladder WINDOW (batches of per-instance matrices on the resident float32 / streaming kernels): only kwin = RQP_WINDOW
+    // of the nrho entries of K(rho) exist per matrix -- the reference builds all of them (reluqpth.py:52-78) although a solve
+    // visits 2-4.  An instance whose index leaves its window at a check exits with its exact state (x, z, lam, A x, carried
+    // rho estimate, iteration count); rqp_solve re-centres its window, re-factors it and continues the instance: bit-identical
+    // to a solve on the whole ladder.
+    int kwin = 0;                 // slots per matrix (nrho when not windowed)
+    bool windowed = false;
+    int32_t* wbase_d = nullptr;   // [nmat] ladder index of slot 0
+    double* ax_d = nullptr;       // [B][m] A x of an instance that left its window (exact continuation)
+    int32_t* cstat_d = nullptr;   // [B] 1: left its window, continue after the re-factor
+    int32_t* ncont_d = nullptr;   // instances that left their window in the last pass
+    int32_t* ncont_h = nullptr;   // (pinned host copy)
     // Dispatch order of the per-instance kernels.  Workgroups are issued in grid order and an instance runs as long as its
     // iteration count, so the launch ends with a tail of late, long solves (14 % of the headline launch, measured).  After
     // every solve the instances are ranked by the iteration count they just needed (counting sort on the device) and the next
@@ -97,7 +111,15 @@ struct SolveArgs {
     // its slowest member; once at most `handoff_cols` of its columns are still unsolved at a check, the tile stops and those
     // instances finish on the per-instance resident kernel (`cont` = 1), whose iteration is ~3x shorter than a tile's.
     int handoff_cols;         // MFMA kernel: 0 = off
-    int cont;                 // resident kernel: 1 = only instances with status RQP_STATUS_CONTINUE, resumed at cont_iter
+    int cont;                 // per-instance kernels: 1 = only instances with status RQP_STATUS_CONTINUE (MFMA hand-off), resumed at
+                              // cont_iter with A x recomputed; 2 = only instances with cstat = 1 (they left their rho window),
+                              // resumed exactly: cont_iter >= 0: behind the check of that iteration with A x = ax; < 0: from the
+                              // start of their solve (the incoming rho index was outside the window)
+    const int32_t* wbase;     // [nmat] ladder index of K slot 0 (NULL: 0)
+    int kwin;                 // K slots per matrix
+    double* ax;               // [B][m]
+    int32_t* cstat;           // [B] (NULL: not a windowed handle)
+    int32_t* ncont;
     int32_t* cont_iter;       // [B] iterations done at the hand-off
     double* cont_rho;         // [B] carried rho estimate at the hand-off (Q4)
     const int32_t* order;     // workgroup -> instance (NULL: identity)
@@ -113,6 +135,9 @@ struct SetupArgs {
     double* G;
     const double* rhos;
     double* fscratch;
+    int kwin;                 // K slots per matrix; slot s <-> ladder index (wbase ? wbase[mat] : 0) + s
+    const int32_t* wbase;
+    const int32_t* only;      // [nmat] (NULL: all) build only the matrices with only[mat] != 0 (re-factor of a moved window)
 };
 
 // launchers (defined in the .hip files); return hipError_t of the launch
@@ -134,7 +159,8 @@ hipError_t rqp_launch_scale_vecs(const rqp_handle* h, void* g, void* l, void* u,
 hipError_t rqp_launch_scale_state(const rqp_handle* h, double* x, double* z, double* lam, hipStream_t s);
 hipError_t rqp_launch_unscale_out(const rqp_handle* h, void* x, void* z, void* lam, double* obj, hipStream_t s);
 hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s);
-hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s);
+hipError_t rqp_launch_get_K(const rqp_handle* h, const void* Kmat, void* out, hipStream_t s);
+hipError_t rqp_launch_rewindow(const rqp_handle* h, int all, hipStream_t s);
 
 // one-time launch preparation (dynamic-LDS function attributes), called from rqp_setup for the selected kernels
 hipError_t rqp_prepare_generic(const rqp_handle* h);
@@ -145,7 +171,7 @@ size_t rqp_generic_lds_bytes(const rqp_handle* h);
 // resident (register/LDS) variant, float32 only
 bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
-hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, const int32_t* only, hipStream_t s);
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 bool rqp_res64_fits(const rqp_handle* h);

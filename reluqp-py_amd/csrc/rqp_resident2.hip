@@ -153,9 +153,11 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
     const size_t mat = (a.sA == 0) ? 0 : (size_t)b;
     const float* cg = (const float*)a.c + (size_t)b * m;
-    // continue mode (SolveArgs.cont): only the instances the MFMA kernel handed over, resumed at their iteration count
+    // continue modes (SolveArgs.cont).  1: only the instances the MFMA kernel handed over, resumed at their iteration count
+    // with A x recomputed.  2: only the instances that left their rho window (cstat = 1), resumed EXACTLY where they stopped.
     int k0 = 0;
-    if (a.cont) {
+    bool exact = false;                                            // resume behind the check of iteration k0 with A x = ax
+    if (a.cont == 1) {
         if (a.info.status[b] != RQP_STATUS_CONTINUE) {             // (uniform per workgroup)
             if (!a.warm_starting) {                                // the first kernel kept every state for this pass: clear it
                 for (int i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = 0.0;
@@ -168,6 +170,26 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
             return;
         }
         k0 = a.cont_iter[b];
+    } else if (a.cont == 2) {
+        if (a.cstat[b] == 0) return;
+        const int ci = a.cont_iter[b];
+        if (ci >= 0) {
+            k0 = ci;
+            exact = true;
+        }
+    }
+    // rho window: K slot s of this matrix holds ladder index wb + s
+    const int wb = a.wbase ? a.wbase[mat] : 0;
+    if (a.cstat && a.mode == 0) {
+        const int sl = a.rho_ind[b] - wb;
+        if (sl < 0 || sl >= a.kwin) {                              // (uniform) the incoming index lies outside the window: leave
+            if (tid == 0) {                                        // untouched; rqp_solve re-centres the window and restarts it
+                a.cstat[b] = 1;
+                if (!exact) a.cont_iter[b] = -1;
+                atomicAdd(a.ncont, 1);
+            }
+            return;
+        }
     }
 
     // ---- matrices: A, K_j -> VGPR pairs ; H -> LDS  (each element read from HBM once per solve)
@@ -192,21 +214,23 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     // lane (rr, cc) takes the row pairs of its rows, columns KC cc .. KC cc + KC - 1: the 8 lanes of a row group read one
     // whole row between them, so every cache line is fetched once.  No packed copy of the table (3.9 GB and 1.3 ms of setup
     // at B = 4096); the guarded 4-byte loads make a K load ~2x slower, +0.9 % per solve (A/B, tools/ab_bench.sh).
-    auto load_K = [&](int j) {
+    auto load_K = [&](int jl) {
+        int j = jl - wb;                                            // K slot (modes 1 / 2 of a windowed handle: rqp_iterate /
+        j = j < 0 ? 0 : (j >= a.kwin ? a.kwin - 1 : j);             // rqp_compute_residuals re-centre the windows first)
         if constexpr (!KD) {
-            const kpair_t* Kp = (const kpair_t*)Kpack + (mat * a.nrho + j) * (size_t)KE2 * NT + tid;
+            const kpair_t* Kp = (const kpair_t*)Kpack + (mat * a.kwin + j) * (size_t)KE2 * NT + tid;
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
                 for (int c = 0; c < KC; ++c) kr[kp][c] = Kp[(size_t)(kp * KC + c) * NT];
-            if constexpr (KH) kscale = Kscale[mat * a.nrho + j];
+            if constexpr (KH) kscale = Kscale[mat * a.kwin + j];
         } else {
             // (lane-derived offsets through an opaque copy: otherwise the addresses and predicates of this rare path are
             //  hoisted out of the solve loop and cost it registers)
             int lane_o = lane, wave_o = wave;
             asm volatile("" : "+v"(lane_o), "+v"(wave_o));
             const int rr = lane_o >> 3, cc = lane_o & 7, wave = wave_o;
-            const float* Kj = (const float*)a.K + ((a.sK == 0) ? (size_t)0 : (size_t)b * a.sK) + (size_t)j * n * a.ldn;
+            const float* Kj = (const float*)a.K + ((a.sK == 0) ? (size_t)0 : (size_t)b * a.sK) + (size_t)j * n * a.ldn;     // (j: slot)
             // Unguarded vector loads (4-byte aligned float4: the rows start at multiples of ldn floats, the lane's run at KC cc):
             //  * columns >= n over-read into the next row (the table is allocated with a zeroed tail): those K entries meet
             //    d = 0 exactly -- the A and H images are zero-padded, so the padding columns of d are 0 -- and K is finite;
@@ -246,7 +270,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     };
     for (int i = tid; i < M; i += NT) {
         const bool in = i < m;
-        zt64[i] = 0.0;
+        zt64[i] = (exact && in) ? a.ax[(size_t)b * m + i] : 0.0;
         z64[i] = in ? a.z[(size_t)b * m + i] : 0.0;
         lam64[i] = in ? a.lam[(size_t)b * m + i] : 0.0;
         lT[i] = in ? ((const float*)a.l)[(size_t)b * m + i] : 0.f;
@@ -521,21 +545,23 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         }
     };
 
-    float rho_est = (a.mode == 2) ? (float)a.rho_in : (a.cont ? (float)a.cont_rho[b] : (float)a.rhos[ri]);   // reluqpth.py:211
+    float rho_est = (a.mode == 2) ? (float)a.rho_in : ((a.cont == 1 || exact) ? (float)a.cont_rho[b] : (float)a.rhos[ri]);   // reluqpth.py:211
     float pri = 0.f, dua = 0.f;
     bool converged = false;
     int iters = k0;
     const float tolT = (float)a.tol;
     const int kmax = (a.mode == 2) ? 0 : a.max_iter;
 
-    // ---- A x and H x of the incoming state
-    {
+    // ---- A x of the incoming state (an exact continuation brought it along: only lam_hat / nu of the next iteration are due)
+    if (!exact) {
         float vc0[CQ];
         load_vc(xin, vc0);
         prod_A(vc0);
+        __syncthreads();
+        row_pass(true, false, kmax > k0);
+    } else {
+        row_pass(false, false, kmax > k0);
     }
-    __syncthreads();
-    row_pass(true, false, kmax > k0);
 
     // ---- compute_residuals (reluqpth.py:307-318) on the current state (hx = H x valid)
     float scl_p = 0.f, scl_d = 0.f;                                    // residual scales of the last check (eps_rel)
@@ -683,6 +709,27 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
                 break;
             }
             if (ri != ri_before) {                                     // adaptive-rho "re-factor": table lookup
+                if (a.cstat && k < kmax && (ri < wb || ri >= wb + a.kwin)) {
+                    // the new index has no K in this instance's window: leave with the exact state; rqp_solve re-factors a
+                    // window around ri and continues the instance behind this check (SolveArgs.cont = 2)
+                    // (indices from an opaque copy of tid: this rare path must not cost the solve loop hoisted address registers)
+                    int tid_o = tid;
+                    asm volatile("" : "+v"(tid_o));
+                    for (int i = tid_o; i < n; i += NT) a.x[(size_t)b * n + i] = x64[SW * (i / CW) + i % CW];
+                    for (int i = tid_o; i < m; i += NT) {
+                        a.z[(size_t)b * m + i] = z64[i];
+                        a.lam[(size_t)b * m + i] = lam64[i];
+                        a.ax[(size_t)b * m + i] = zt64[i];
+                    }
+                    if (tid_o == 0) {
+                        a.rho_ind[b] = ri;
+                        a.cont_iter[b] = k;
+                        a.cont_rho[b] = (double)rho_est;
+                        a.cstat[b] = 1;
+                        atomicAdd(a.ncont, 1);
+                    }
+                    return;
+                }
                 load_K(ri);
                 set_rho_rows(ri);
                 // wait for the K loads HERE: left pending, the compiler guards every first use of a K register in the solve
@@ -732,6 +779,7 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
     if (a.out_z) for (int i = tid; i < m; i += NT) ((float*)a.out_z)[(size_t)b * m + i] = (float)z64[i];
     if (a.out_lam) for (int i = tid; i < m; i += NT) ((float*)a.out_lam)[(size_t)b * m + i] = (float)lam64[i];
     if (tid == 0) {
+        if (a.cstat) a.cstat[b] = 0;
         if (a.info.iter) a.info.iter[b] = converged ? iters : a.max_iter;
         if (a.last_iter) a.last_iter[b] = converged ? iters : a.max_iter;
         if (a.info.status) a.info.status[b] = converged ? RQP_STATUS_SOLVED : ((pri != pri || dua != dua) ? RQP_STATUS_NAN : RQP_STATUS_MAX_ITER);
@@ -767,9 +815,10 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 template <class C, bool KH>
 __global__ void k_pack_res2(int n, int m, int ldn, int nrho, int xoff, const float* __restrict__ A, const float* __restrict__ Ht,
                             const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
-                            float* __restrict__ Hpack, float* __restrict__ Kscale) {
+                            float* __restrict__ Hpack, float* __restrict__ Kscale, const int32_t* __restrict__ only) {
     constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR;
-    const int mat = blockIdx.y;
+    const int mat = blockIdx.y;                                    // (nrho here = K slots per matrix, rqp_handle.kwin)
+    if (only && !only[mat]) return;                                // re-pack of moved windows only
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
     const float* Am = A + (size_t)mat * m * ldn;
@@ -862,7 +911,7 @@ bool rqp_res2_fits(const rqp_handle* h) { return res2_pick(h) >= 0; }
 template <class C>
 static void pack_elems_t(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
     *a_elems = (size_t)h->nmat * C::AE2 * C::NT * 2;
-    *k_elems = h->k_direct ? 0 : (size_t)h->nmat * h->nrho * C::KE2 * C::NT * (h->dims.tile_dtype == RQP_TILE_F16 ? 1 : 2);
+    *k_elems = h->k_direct ? 0 : (size_t)h->nmat * h->kwin * C::KE2 * C::NT * (h->dims.tile_dtype == RQP_TILE_F16 ? 1 : 2);
     *h_elems = (size_t)h->nmat * C::HU * C::NT * 4;
 }
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems) {
@@ -875,29 +924,32 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
 }
 
 template <class C>
-static hipError_t pack_t(const rqp_handle* h, hipStream_t s) {
+static hipError_t pack_t(const rqp_handle* h, const int32_t* only, hipStream_t s) {
     const size_t stage_ah = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
     const size_t stage_k = (size_t)h->n * h->ldn * sizeof(float);
+    // only != NULL: the K blocks of the matrices whose window moved (A and H have not changed)
     if (h->dims.tile_dtype == RQP_TILE_F16) {
-        k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->nrho, 0, (const float*)h->A, (const float*)h->Ht,
-                                                                     (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
-        k_pack_res2<C, true><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
-                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale);
+        if (!only)
+            k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)h->A, (const float*)h->Ht,
+                                                                         (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, nullptr);
+        k_pack_res2<C, true><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)h->A, (const float*)h->Ht,
+                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, only);
     } else {
-        k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->nrho, 0, (const float*)h->A, (const float*)h->Ht,
-                                                                      (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+        if (!only)
+            k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)h->A, (const float*)h->Ht,
+                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
         if (!h->k_direct)       // (low-memory handles read K from the row-major table: only the (A, H) images)
-            k_pack_res2<C, false><<<dim3(h->nrho, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->nrho, 1, (const float*)h->A, (const float*)h->Ht,
-                                                                               (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr);
+            k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)h->A, (const float*)h->Ht,
+                                                                               (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, only);
     }
     return hipGetLastError();
 }
-hipError_t rqp_launch_pack_res2(const rqp_handle* h, hipStream_t s) {
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, const int32_t* only, hipStream_t s) {
     switch (res2_pick(h)) {
-        case 0: return pack_t<Cfg2C4>(h, s);
-        case 1: return pack_t<Cfg2M>(h, s);
-        case 3: return pack_t<Cfg2N>(h, s);
-        default: return pack_t<Cfg2C2>(h, s);
+        case 0: return pack_t<Cfg2C4>(h, only, s);
+        case 1: return pack_t<Cfg2M>(h, only, s);
+        case 3: return pack_t<Cfg2N>(h, only, s);
+        default: return pack_t<Cfg2C2>(h, only, s);
     }
 }
 

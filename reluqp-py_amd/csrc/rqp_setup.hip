@@ -301,13 +301,14 @@ template <typename T, bool LDS_MODE>
 __global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = a.n;
-    const int mat = blockIdx.x / a.nrho, j = blockIdx.x % a.nrho;
+    const int mat = blockIdx.x / a.kwin, j = blockIdx.x % a.kwin;        // j: K slot; ladder index = window base + slot
+    if (a.only && !a.only[mat]) return;
     double* colb = (double*)smem_raw;            // [n]   column k before the sweep
     double* rowb = colb + n;                     // [n]   scaled pivot row
     double* M = LDS_MODE ? (rowb + n) : (a.fscratch + (size_t)blockIdx.x * n * n);
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
-    const double rho = a.rhos[j];
+    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + j];
     const int tid = threadIdx.x;
     for (int i = tid; i < n * n; i += 256) {
         int r = i / n, c = i % n;
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
         }
         __syncthreads();
     }
-    T* K = (T*)a.K + ((size_t)mat * a.nrho + j) * n * a.ldn;
+    T* K = (T*)a.K + ((size_t)mat * a.kwin + j) * n * a.ldn;
     for (int i = tid; i < n * a.ldn; i += 256) {
         int r = i / a.ldn, c = i % a.ldn;
         // symmetrise the rounded result so that column-oriented products see one matrix
@@ -351,13 +352,14 @@ __global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int RS = 256 / CN;                 // row slices
     const int n = a.n;
-    const int mat = blockIdx.x / a.nrho, j = blockIdx.x % a.nrho;
+    const int mat = blockIdx.x / a.kwin, j = blockIdx.x % a.kwin;
+    if (a.only && !a.only[mat]) return;
     double* colb = (double*)smem_raw;            // [n] column k before the sweep
     double* rowb = colb + n;                     // [n] scaled pivot row
     double* M = rowb + n;                        // [n][n] row-major (consecutive c -> consecutive banks); 2 WGs/CU at n = 100
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
-    const double rho = a.rhos[j];
+    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + j];
     const int tid = threadIdx.x, c = tid & (CN - 1), rs = tid / CN;
     const bool cin = c < n;
     if (cin)
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
         }
         __syncthreads();
     }
-    T* K = (T*)a.K + ((size_t)mat * a.nrho + j) * n * a.ldn;
+    T* K = (T*)a.K + ((size_t)mat * a.kwin + j) * n * a.ldn;
     for (int r = rs; r < n; r += RS)
         if (c < a.ldn) K[(size_t)r * a.ldn + c] = cin ? (T)(0.5 * (M[r * n + c] + M[c * n + r])) : T(0);
 }
@@ -427,11 +429,12 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     __shared__ __attribute__((aligned(16))) double rowbuf[2][NMAX];
     __shared__ __attribute__((aligned(16))) double tb[RT][16][17];       // one output pass: RT blocks, closed under transposition
     const int n = a.n;
-    const int mat = blockIdx.x / a.nrho, jrho = blockIdx.x % a.nrho;
+    const int mat = blockIdx.x / a.kwin, jrho = blockIdx.x % a.kwin;     // jrho: K slot; ladder index = window base + slot
+    if (a.only && !a.only[mat]) return;                                   // (uniform) re-factor of moved windows only
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
-    const double rho = a.rhos[jrho];
+    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + jrho];
     double mreg[RT][RT];                                                  // blocks i <= j only
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     // (i, (d - i) mod RT): an upper block comes from the thread's own registers, a lower block (i, j), i > j, is the
     // transpose of block (j, i) of thread (tx, ty) -- slot j of the same pass -- and a diagonal block averages the two
     // roundings of (r, c) and (c, r), which both exist there.
-    T* K = (T*)a.K + ((size_t)mat * a.nrho + jrho) * n * a.ldn;
+    T* K = (T*)a.K + ((size_t)mat * a.kwin + jrho) * n * a.ldn;
 #pragma unroll
     for (int d = 0; d < RT; ++d) {
         __syncthreads();
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
 
 template <typename T, int RT>
 static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
-    k_factor_reg2<T, RT><<<h->nmat * h->nrho, 256, 0, s>>>(a);
+    k_factor_reg2<T, RT><<<a.nmat * a.kwin, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 
@@ -524,7 +527,7 @@ static hipError_t launch_factor_fast(rqp_handle* h, const SetupArgs& a, hipStrea
     const size_t lds = (2 * (size_t)h->n + (size_t)h->n * h->n) * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*)k_factor_fast<T, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_factor_fast<T, CN><<<h->nmat * h->nrho, 256, lds, s>>>(a);
+    k_factor_fast<T, CN><<<a.nmat * a.kwin, 256, lds, s>>>(a);
     return hipGetLastError();
 }
 
@@ -539,7 +542,7 @@ hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
         return h->esz == 4 ? launch_factor_fast<float, 128>(h, a, s) : launch_factor_fast<double, 128>(h, a, s);
     const size_t lds_need = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);
     const bool lds_mode = lds_need <= 160 * 1024 - 512;
-    const int grid = h->nmat * h->nrho;
+    const int grid = a.nmat * a.kwin;
     hipError_t e;
     if (lds_mode) {
         if (h->esz == 4) {
@@ -650,11 +653,28 @@ __global__ void k_get_K(int n, int ldn, const T* K, T* out) {
         out[i] = K[(size_t)(i / n) * ldn + (i % n)];
 }
 
-hipError_t rqp_launch_get_K(const rqp_handle* h, int b, int j, void* out, hipStream_t s) {
-    const size_t off = ((size_t)(h->dims.shared_mats ? 0 : b) * h->nrho + j) * h->n * h->ldn;
+// Kmat: one n x ldn matrix of the K table (or of a scratch copy a single-matrix factor call just filled)
+hipError_t rqp_launch_get_K(const rqp_handle* h, const void* Kmat, void* out, hipStream_t s) {
     if (h->esz == 4)
-        k_get_K<float><<<64, 256, 0, s>>>(h->n, h->ldn, (const float*)h->K + off, (float*)out);
+        k_get_K<float><<<64, 256, 0, s>>>(h->n, h->ldn, (const float*)Kmat, (float*)out);
     else
-        k_get_K<double><<<64, 256, 0, s>>>(h->n, h->ldn, (const double*)h->K + off, (double*)out);
+        k_get_K<double><<<64, 256, 0, s>>>(h->n, h->ldn, (const double*)Kmat, (double*)out);
+    return hipGetLastError();
+}
+
+// Window bookkeeping of a windowed handle.  all = 0: the instances that left their window mid-solve (cstat = 1) get a window
+// centred on their current index.  all = 1 (before rqp_iterate / rqp_compute_residuals, which run no exit-and-continue
+// protocol): every instance whose index lies outside its window is marked (cstat = 1) and re-centred, the others cleared.
+__global__ void k_rewindow(int B, int nrho, int kwin, int all, const int32_t* __restrict__ rho_ind, int32_t* __restrict__ cstat,
+                           int32_t* __restrict__ wbase) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const int ri = rho_ind[b];
+        if (all) cstat[b] = (ri < wbase[b] || ri >= wbase[b] + kwin) ? 1 : 0;
+        if (cstat[b]) wbase[b] = min(max(ri - kwin / 2, 0), nrho - kwin);
+    }
+}
+
+hipError_t rqp_launch_rewindow(const rqp_handle* h, int all, hipStream_t s) {
+    k_rewindow<<<(h->B + 255) / 256, 256, 0, s>>>(h->B, h->nrho, h->kwin, all, h->rho_ind, h->cstat_d, h->wbase_d);
     return hipGetLastError();
 }

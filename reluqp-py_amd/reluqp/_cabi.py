@@ -15,6 +15,7 @@ RQP_TILE_SAME, RQP_TILE_F16 = 0, 1
 KERNELS = {"auto": 0, "generic": 1, "resident": 2, "resident2": 2, "wave": 3, "mfma": 4}     # enum rqp_kernel
 RQP_ERR_UNSUPPORTED = -5
 FLAG_LOW_MEMORY = 1          # rqp_dims.flags
+FLAG_FULL_LADDER = 2
 STATUS_STR = {0: "solved", 1: "max_iters_reached", 2: "nan_detected", 3: "primal_infeasible", 4: "dual_infeasible",
               -1: "unsolved"}
 
@@ -23,7 +24,7 @@ ABI_SYMBOLS = (
     "rqp_default_settings", "rqp_create", "rqp_setup", "rqp_update", "rqp_update_mats", "rqp_update_affine",
     "rqp_update_settings",
     "rqp_warm_start", "rqp_clear_primal_dual", "rqp_solve", "rqp_iterate", "rqp_compute_residuals",
-    "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_dispatch_history", "rqp_get_dispatch", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
+    "rqp_get_state", "rqp_get_rhos", "rqp_get_K", "rqp_dispatch_history", "rqp_get_dispatch", "rqp_get_window", "rqp_kernel_name", "rqp_destroy", "rqp_strerror",
     "rqp_last_error", "rqp_version",
 )
 
@@ -100,6 +101,7 @@ def load():
         "rqp_get_K": (ctypes.c_int, [H, i32, i32, vp, vp]),
         "rqp_dispatch_history": (ctypes.c_int, [H, i32]),
         "rqp_get_dispatch": (ctypes.c_int, [H, vp, vp, ctypes.POINTER(i32), vp]),
+        "rqp_get_window": (ctypes.c_int, [H, ctypes.POINTER(i32), vp, vp]),
         "rqp_kernel_name": (ctypes.c_char_p, [H]),
         "rqp_destroy": (ctypes.c_int, [H]),
         "rqp_strerror": (ctypes.c_char_p, [ctypes.c_int]),

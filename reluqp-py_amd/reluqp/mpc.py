@@ -253,18 +253,11 @@ class LinearMPC(object):
                 step()
             torch.cuda.current_stream(device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            # no finaliser may run while the stream is capturing: the capture mode is global, so a collected solver object
-            # (rqp_destroy -> hipFree) or tensor anywhere in the process would invalidate it (seen once in a long test session)
-            import gc
-            gc.collect()
-            gc_was_on = gc.isenabled()
-            gc.disable()
-            try:
-                with torch.cuda.graph(graph):
-                    step()
-            finally:
-                if gc_was_on:
-                    gc.enable()
+            # thread-local capture error mode: frees / allocations on OTHER threads cannot invalidate the capture; on this
+            # thread rqp_destroy (a finaliser, an explicit del) frees its workspace under the relaxed capture mode
+            # (csrc/rqp_abi.hip: free_ws), so destroying a solver mid-capture is safe too (tests/test_mpc_gpu.py)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step()
             done = 1                                          # the warm-up ran one step (capturing only records)
             for _ in range(max(0, steps - done)):
                 graph.replay()

@@ -136,7 +136,8 @@ class ReLU_QP(object):
               kernel="auto",
               iterate_dtype=None,
               devices=None,
-              low_memory=False):
+              low_memory=False,
+              full_ladder=False):
         """
         Setup ReLU-QP solver problem of the form
 
@@ -155,7 +156,11 @@ class ReLU_QP(object):
         contiguously over several GPUs inside this process (one handle and stream per device, results gathered on
         devices[0]; no collective -- reluqp/multidevice.py).  ``low_memory=True`` (rqp_dims.flags RQP_FLAG_LOW_MEMORY): the
         resident float32 kernel reads K(rho) from the factor kernel's table instead of a packed copy -- 43 % less workspace,
-        12 % less setup time, 1 % more solve time, bit-identical results.
+        12 % less setup time, 1 % more solve time, bit-identical results.  ``full_ladder=True`` (RQP_FLAG_FULL_LADDER): build
+        K(rho) for every entry of the rho ladder of every matrix as the reference does (reluqpth.py:52-78); by default batches
+        of >= 32 per-instance matrices keep a window of 5 entries around each instance's index and re-factor on demand
+        (bit-identical results, ~3x less setup time and workspace; solve() then synchronises the stream, so use
+        full_ladder=True under HIP-graph capture).
         """
         if devices is not None:
             from reluqp.multidevice import DeviceShards
@@ -167,7 +172,7 @@ class ReLU_QP(object):
                       adaptive_rho_tolerance=adaptive_rho_tolerance, max_iter=max_iter, eps_abs=eps_abs,
                       check_interval=check_interval, precision=precision, eq_tol=eq_tol, eps_rel=eps_rel,
                       check_infeasibility=check_infeasibility, eps_prim_inf=eps_prim_inf, eps_dual_inf=eps_dual_inf,
-                      kernel=kernel, iterate_dtype=iterate_dtype, low_memory=low_memory)
+                      kernel=kernel, iterate_dtype=iterate_dtype, low_memory=low_memory, full_ladder=full_ladder)
             self._shards = DeviceShards(ReLU_QP, list(devices), H, g, A, l, u, kw)
             first = self._shards.children[0]
             self.settings, self.QP, self.layers, self._rhos = first.settings, first.QP, first.layers, first._rhos
@@ -208,7 +213,8 @@ class ReLU_QP(object):
             qp = self.QP
             dims = _cabi.Dims(n=qp.nx, m=qp.nc, batch=qp.batch, shared_mats=int(qp.shared_mats),
                               dtype=_cabi.RQP_F32 if precision == torch.float32 else _cabi.RQP_F64,
-                              kernel=_cabi.KERNELS[kernel], tile_dtype=tile, flags=_cabi.FLAG_LOW_MEMORY if low_memory else 0)
+                              kernel=_cabi.KERNELS[kernel], tile_dtype=tile,
+                              flags=(_cabi.FLAG_LOW_MEMORY if low_memory else 0) | (_cabi.FLAG_FULL_LADDER if full_ladder else 0))
             cs = self._csettings()
             h = ctypes.c_void_p()
             _cabi.check(None, lib.rqp_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(cs), device.index),
@@ -479,6 +485,19 @@ class ReLU_QP(object):
         (default), False / 0 = off (every launch in grid order, like the first solve of a fresh handle), 2 = forget now."""
         self._need_setup()
         _cabi.check(self._h, _cabi.load().rqp_dispatch_history(self._h, int(mode)), "rqp_dispatch_history")
+
+    def get_window(self):
+        """(slots, wbase): K(rho) slots per matrix and, on a windowed handle, the int32 tensor [batch] of the ladder index of
+        slot 0 of every instance's window (None when the whole ladder is built)."""
+        self._need_setup()
+        st = self.settings
+        with torch.cuda.device(st.device):
+            wb = torch.full((self.QP.batch,), -1, device=st.device, dtype=torch.int32)
+            slots = ctypes.c_int32(0)
+            _cabi.check(self._h, _cabi.load().rqp_get_window(self._h, ctypes.byref(slots), wb.data_ptr(), self._stream()),
+                        "rqp_get_window")
+            torch.cuda.current_stream(st.device).synchronize()
+        return slots.value, (wb if slots.value < len(self._rhos) else None)
 
     def get_dispatch(self):
         """(order, last_iter) int32 tensors [batch] the next launch would be issued by, or None when no order is recorded."""

@@ -239,3 +239,37 @@ def test_closed_loop_graph_replay_matches_eager():
     xb, itb = ctl_b.simulate_graph(xb.cpu().numpy(), 12, dev, torch.float32)
     assert abs(ita - itb) < 1e-9
     np.testing.assert_allclose(xb.cpu().numpy(), xa.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_solver_destroyed_during_graph_capture_keeps_the_capture_valid():
+    """A solver object dies (rqp_destroy -> hipFree of its workspace) while this thread captures the control step of ANOTHER
+    solver: the capture must stay valid and replay correctly (free_ws frees under the relaxed capture mode; the capture
+    itself runs in the thread-local error mode).  Round-2 finding: a finaliser's hipFree invalidated a global-mode capture."""
+    import reluqp.reluqpth as reluqpth
+    dev = torch.device("cuda:0")
+    ctl, x0 = _setup("condensed", nx=6, nu=2, N=10, seed=8, B=32)
+    ctl.simulate_device(x0, 1, dev, torch.float32)                    # sets the solver up
+    g, l, u = ctl.qp_vectors(x0)
+    victim = reluqpth.ReLU_QP()
+    victim.setup(ctl.H, g, ctl.A, l, u, device=dev, precision=torch.float32)
+    victim.solve()
+    solver = ctl.solver
+    solver.synchronous = False
+    out = {}
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        out["r"] = solver.solve()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        victim._destroy()                                             # hipFree x ~25 in the middle of the capture
+        out["r"] = solver.solve()
+    del victim
+    graph.replay()
+    torch.cuda.synchronize()
+    solver.synchronous = True
+    ref = solver.solve()                                              # eager re-solve of the same (warm) state
+    assert bool((out["r"].info.status_code == 0).all()) and bool((ref.info.status_code == 0).all())
+    assert float((out["r"].x - ref.x).abs().max()) < 1e-3
