@@ -74,6 +74,8 @@ def parse():
                     help="random_qp: the headline metric's workload (default); mpc: BASELINE config 3, batch of condensed "
                          "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A; c4: BASELINE config 4, "
                          "random dense QPs n=32, m=64")
+    ap.add_argument("--full-ladder", action="store_true", help="setup(full_ladder=True): K(rho) for all 18 ladder entries of every "
+                    "matrix as the reference builds them (default: a window of 5 with exact continuation)")
     ap.add_argument("--fresh-batches", type=int, default=4, help="distinct synthetic batches (one handle each) the timed steps "
                     "rotate through; every solve runs without dispatch history")
     ap.add_argument("--history-steps", type=int, default=5, help="steps of the separately reported with-history leg (0 = skip)")
@@ -273,7 +275,8 @@ def main():
         model = reluqpth.ReLU_QP()
         t0 = time.perf_counter()
         model.setup(Hd, gd, Ad, ld, ud, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False, kernel=args.kernel,
-                    iterate_dtype=torch.float16 if args.tile == "f16" else None, low_memory=args.low_memory)
+                    iterate_dtype=torch.float16 if args.tile == "f16" else None, low_memory=args.low_memory,
+                    full_ladder=args.full_ladder)
         torch.cuda.synchronize(dev)
         setup_times.append(time.perf_counter() - t0)
         model.dispatch_history(False)
@@ -389,7 +392,8 @@ def main():
             "config": {"workload": wl,
                        "global_batch": int(tot_qps), "parallelism": "batch-split x%d, no collectives" % world,
                        "kernel": kernel, "tile": args.tile, "low_memory": bool(args.low_memory),
-                       "fresh_batches": nb, "dispatch_history": False},
+                       "fresh_batches": nb, "dispatch_history": False,
+                       "rho_window": models[0].get_window()[0]},
             "admm_iters_per_sec": tot_iters / step_s,
             "mean_iters": tot_iters / tot_qps,
             "solved_frac": tot_solved / tot_qps,

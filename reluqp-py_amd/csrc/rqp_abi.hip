@@ -587,9 +587,13 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.last_iter = nullptr;
         HIP_TRY(h, rqp_launch_solve_res2(h, c, s));
     }
+    const bool ranks = h->order_d && h->use_history;   // rank the instances by what they just needed: next launch goes longest-first
     if (h->windowed) {
         // instances whose rho index left their window stopped with their exact state: new windows, then they continue
-        // (at most one window move per `RQP_WINDOW / 2` index moves, i.e. per >= 2 checks of an instance)
+        // (at most one window move per `RQP_WINDOW / 2` index moves, i.e. per >= 2 checks of an instance).  The ranking is
+        // enqueued BEFORE the host reads the count (nothing left the window in the common case: the host's wake-up latency
+        // then hides behind it) and again after a continuation pass.
+        if (ranks) HIP_TRY(h, rqp_launch_order_lpt(h, s));
         for (;;) {
             HIP_TRY(h, hipMemcpyAsync(h->ncont_h, h->ncont_d, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
@@ -601,7 +605,9 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
             c.cont = 2;
             c.order = nullptr;
             HIP_TRY(h, launch_solve(h, c, s));
+            if (ranks) HIP_TRY(h, rqp_launch_order_lpt(h, s));
         }
+        if (ranks) h->order_valid = true;
     }
     if (post_cert) {
         SolveArgs c = a;
@@ -611,7 +617,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.keep_state = 0;
         HIP_TRY(h, rqp_launch_solve_generic(h, c, s));
     }
-    if (h->order_d && h->use_history) {             // rank the instances by what they just needed: next launch goes longest-first
+    if (ranks && !h->windowed) {
         HIP_TRY(h, rqp_launch_order_lpt(h, s));
         h->order_valid = true;
     }
