@@ -7,9 +7,27 @@
 #include <cstring>
 #include <algorithm>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "rqp_common.h"
 
-#define RQP_VERSION "rqp-hip 0.2 gfx950"
+hipError_t rqp_raise_lds_limit(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> limit;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = limit[std::make_pair(fn, dev)];
+    if (bytes <= cur) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+
+#define RQP_VERSION "rqp-hip 0.3 gfx950"
 
 namespace {
 

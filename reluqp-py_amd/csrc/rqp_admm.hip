@@ -477,8 +477,8 @@ size_t rqp_generic_lds_bytes(const rqp_handle* h) {
 hipError_t rqp_prepare_generic(const rqp_handle* h) {
     const size_t lds = rqp_generic_lds_bytes(h);
     if (lds <= 48 * 1024) return hipSuccess;
-    return h->esz == 4 ? hipFuncSetAttribute((const void*)k_admm_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                       : hipFuncSetAttribute((const void*)k_admm_generic<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return h->esz == 4 ? rqp_raise_lds_limit((const void*)k_admm_generic<float>, (size_t)lds)
+                       : rqp_raise_lds_limit((const void*)k_admm_generic<double>, (size_t)lds);
 }
 
 hipError_t rqp_launch_solve_generic(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

@@ -186,4 +186,9 @@ size_t rqp_mfma_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
+// Raise -- never lower -- the dynamic-LDS limit of kernel `fn` on the current device.  The attribute belongs to the FUNCTION, not
+// to a handle: a later, smaller handle must not shrink the limit an earlier, larger handle's launches rely on (process-wide
+// maximum per function and device, rqp_abi.hip).
+hipError_t rqp_raise_lds_limit(const void* fn, size_t bytes);
+
 static inline int rqp_round_up(int v, int q) { return (v + q - 1) / q * q; }

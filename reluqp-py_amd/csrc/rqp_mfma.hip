@@ -902,9 +902,9 @@ hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s) {
 }
 hipError_t rqp_prepare_mfma(const rqp_handle* h) {
     const size_t lds = CfgM55::lds_floats() * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = rqp_raise_lds_limit((const void*)k_admm_mfma<CfgM55, false>, (size_t)lds);
     if (e == hipSuccess && (h->debug & 2))
-        e = hipFuncSetAttribute((const void*)k_admm_mfma<CfgM55, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = rqp_raise_lds_limit((const void*)k_admm_mfma<CfgM55, true>, (size_t)lds);
     return e;
 }
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {

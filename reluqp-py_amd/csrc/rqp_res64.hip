@@ -478,9 +478,9 @@ bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N &
 
 hipError_t rqp_prepare_res64(const rqp_handle* h) {
     const int lds = (int)(r64_lds_doubles() * sizeof(double));
-    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = rqp_raise_lds_limit((const void*)k_admm_res64<false>, (size_t)lds);
     if (e == hipSuccess && (h->debug & 2))
-        e = hipFuncSetAttribute((const void*)k_admm_res64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        e = rqp_raise_lds_limit((const void*)k_admm_res64<true>, (size_t)lds);
     return e;
 }
 

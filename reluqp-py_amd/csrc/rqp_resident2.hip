@@ -959,19 +959,19 @@ static hipError_t prepare_t(const rqp_handle* h) {
     {   // pack kernel: its LDS stage holds a whole source matrix (up to m x ldn floats = 128 KB on the big tile)
         const size_t stage = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
         hipError_t pe = (h->dims.tile_dtype == RQP_TILE_F16)
-                            ? hipFuncSetAttribute((const void*)k_pack_res2<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage)
-                            : hipFuncSetAttribute((const void*)k_pack_res2<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage);
+                            ? rqp_raise_lds_limit((const void*)k_pack_res2<C, true>, (size_t)stage)
+                            : rqp_raise_lds_limit((const void*)k_pack_res2<C, false>, (size_t)stage);
         if (pe != hipSuccess) return pe;
     }
     if (h->dims.tile_dtype == RQP_TILE_F16)
-        return hipFuncSetAttribute((const void*)k_admm_res2<C, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return rqp_raise_lds_limit((const void*)k_admm_res2<C, false, true>, (size_t)lds);
+    hipError_t e = rqp_raise_lds_limit((const void*)k_admm_res2<C, false, false>, (size_t)lds);
     if (e != hipSuccess) return e;
     if (h->k_direct) {
-        e = hipFuncSetAttribute((const void*)k_admm_res2<C, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = rqp_raise_lds_limit((const void*)k_admm_res2<C, false, false, true>, (size_t)lds);
         if (e != hipSuccess) return e;
     }
-    if (h->debug & 2) e = hipFuncSetAttribute((const void*)k_admm_res2<C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (h->debug & 2) e = rqp_raise_lds_limit((const void*)k_admm_res2<C, true, false>, (size_t)lds);
     if (h->debug & 1) {
         int nb = -1;
         hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_admm_res2<C, false, false>, C::NT, lds);

@@ -525,7 +525,7 @@ static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStrea
 template <typename T, int CN>
 static hipError_t launch_factor_fast(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     const size_t lds = (2 * (size_t)h->n + (size_t)h->n * h->n) * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void*)k_factor_fast<T, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = rqp_raise_lds_limit((const void*)k_factor_fast<T, CN>, (size_t)lds);
     if (e != hipSuccess) return e;
     k_factor_fast<T, CN><<<a.nmat * a.kwin, 256, lds, s>>>(a);
     return hipGetLastError();
@@ -546,13 +546,11 @@ hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     hipError_t e;
     if (lds_mode) {
         if (h->esz == 4) {
-            e = hipFuncSetAttribute((const void*)k_factor<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_need);
+            e = rqp_raise_lds_limit((const void*)k_factor<float, true>, (size_t)lds_need);
             if (e != hipSuccess) return e;
             k_factor<float, true><<<grid, 256, lds_need, s>>>(a);
         } else {
-            e = hipFuncSetAttribute((const void*)k_factor<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_need);
+            e = rqp_raise_lds_limit((const void*)k_factor<double, true>, (size_t)lds_need);
             if (e != hipSuccess) return e;
             k_factor<double, true><<<grid, 256, lds_need, s>>>(a);
         }

@@ -8,6 +8,8 @@ each shard's outputs at the end.  (``torch.distributed`` + one process per GPU i
 ``reluqp.distributed`` / ``bench.py --gpus N``.)  A device may appear several times (two shards on one GPU run on two
 streams), which is also how the path is tested on a one-GPU box.
 """
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
 from reluqp import _cabi
@@ -29,26 +31,32 @@ class DeviceShards(object):
             raise ValueError("batch of %d cannot be split over %d devices" % (self.batch, world))
         self.ranges = [shard_range(self.batch, r, world) for r in range(world)]
         shared = H.dim() == 2
-        self.children, self.streams = [], []
-        for dev, (s0, sz) in zip(self.devices, self.ranges):
-            sl = slice(s0, s0 + sz)
-            child = owner_cls()
+        self.children = [owner_cls() for _ in self.devices]
+        self.streams = []
+        for child, dev in zip(self.children, self.devices):
             child.synchronous = False                       # enqueue only; this class waits once for all shards
             with torch.cuda.device(dev):
-                stream = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(stream):
-                    child.setup(H if shared else H[sl], g[sl], A if shared else A[sl], l[sl], u[sl], device=dev, **setup_kw)
-            self.children.append(child)
-            self.streams.append(stream)
+                self.streams.append(torch.cuda.Stream(device=dev))
+        # One host thread per shard ("one host thread (or process) per GPU to avoid serialising launches"):
+        # every shard's setup chain is enqueued before anything is waited for, and a call that blocks inside the library
+        # (the count read-back of a windowed rqp_solve) only blocks its own thread -- ctypes releases the GIL for the call.
+        self._pool = ThreadPoolExecutor(max_workers=len(self.devices)) if len(self.devices) > 1 else None
+        self._each(lambda c, sl: c.setup(H if shared else H[sl], g[sl], A if shared else A[sl], l[sl], u[sl],
+                                         device=c_dev(c, self), **setup_kw))
+        self._wait()
+        for c in self.children:
+            c._finish_setup_time()
         self.kernel = ",".join(sorted(set(c.kernel for c in self.children)))
 
     # ---- helpers
     def _each(self, fn):
-        out = []
-        for child, dev, stream, (s0, sz) in zip(self.children, self.devices, self.streams, self.ranges):
+        def run(child, dev, stream, rng):
             with torch.cuda.device(dev), torch.cuda.stream(stream):
-                out.append(fn(child, slice(s0, s0 + sz)))
-        return out
+                return fn(child, slice(rng[0], rng[0] + rng[1]))
+        jobs = list(zip(self.children, self.devices, self.streams, self.ranges))
+        if self._pool is None:
+            return [run(*j) for j in jobs]
+        return [f.result() for f in [self._pool.submit(run, *j) for j in jobs]]
 
     def _wait(self):
         for stream in self.streams:
@@ -102,6 +110,13 @@ class DeviceShards(object):
         for c in self.children:
             c._destroy()
         self.children = []
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
+
+
+def c_dev(child, shards):
+    return shards.devices[shards.children.index(child)]
 
 
 def status_strings(codes):

@@ -230,10 +230,18 @@ class ReLU_QP(object):
             self.layers = _Layers(self)
             self.rho_ind = int(np.argmin(np.abs(np.array(list(buf)) - self.settings.rho)))
             end.record()
-            end.synchronize()
-            self.results.info.setup_time = start.elapsed_time(end) / 1000.0
+            if self.synchronous:
+                end.synchronize()
+                self.results.info.setup_time = start.elapsed_time(end) / 1000.0
+            else:                    # enqueue only (devices=[...]: every shard is set up before anything is waited for)
+                self.results.info.setup_time = 0.0
         self.kernel = lib.rqp_kernel_name(h).decode()
         return None
+
+    def _finish_setup_time(self):
+        """setup_time of a setup() that ran with ``synchronous = False``, once its stream has been waited for."""
+        start, end = self._events()
+        self.results.info.setup_time = start.elapsed_time(end) / 1000.0
 
     # ------------------------------------------------------------------- update
     def update(self, g=None, l=None, u=None, Hx=None, Ax=None):
@@ -428,12 +436,13 @@ class ReLU_QP(object):
         t0 = time.perf_counter()
         o = self._shards.solve()
         run_time = time.perf_counter() - t0
-        info, prec = self.results.info, self.settings.precision
+        info = self.results.info
         self.results.x, self.results.z, self.results.y = o["x"], o["z"], o["y"]
         self.results.lam = self.results.y
         info.iter, info.status_code, info.status, info.rho_ind = o["it"], o["sc"], None, o["ri"]
-        info.pri_res, info.dua_res = o["pri"].to(prec), o["dua"].to(prec)
-        info.rho_estimate, info.obj_val = o["rho"].to(prec), o["obj"].to(prec)
+        # per-instance scalars stay float64 as the kernels wrote them -- the same dtypes as the single-device batch path
+        info.pri_res, info.dua_res = o["pri"], o["dua"]
+        info.rho_estimate, info.obj_val = o["rho"], o["obj"]
         self.rho_ind = o["ri"]
         self.x, self.z, self.lam = self.results.x, self.results.z, self.results.y
         info.run_time = run_time

@@ -531,6 +531,10 @@ def test_devices_list_splits_the_batch(shared):
     rm = multi.solve()
     assert torch.equal(rm.x, x1) and torch.equal(rm.info.iter, it1) and torch.equal(rm.y, y1)
     assert list(rm.info.status) == list(r1.info.status)
+    for f in ("pri_res", "dua_res", "rho_estimate", "obj_val"):      # the same dtypes on both paths (float64, as the kernels write them)
+        assert getattr(rm.info, f).dtype == getattr(r1.info, f).dtype == torch.float64
+        assert torch.equal(getattr(rm.info, f), getattr(r1.info, f))
+    assert multi.results.info.setup_time > 0
     g2 = g * 0.9
     one.update(g=g2)
     multi.update(g=g2)
@@ -542,6 +546,25 @@ def test_devices_list_splits_the_batch(shared):
     assert float(multi.get_state()[0].abs().max()) == 0.0
     with pytest.raises(ValueError):
         reluqpth.ReLU_QP().setup(H if shared else H[0], g[0], A if shared else A[0], l[0], u[0], devices=[0])   # un-batched
+
+
+def test_devices_list_with_windowed_shards():
+    """Shards large enough for the rho-ladder window (>= 32 per-instance matrices each): every shard's rqp_solve reads its
+    continue count back on its own host thread; results equal the single-handle solve bit for bit, also for problems that
+    walk out of their windows (the reference's signed-slack generator at m = 2n ratchets rho upwards)."""
+    import reluqp.reluqpth as reluqpth
+    B, n, n_eq, n_ineq = 130, 20, 10, 30
+    H, g, A, l, u, _ = utils.rand_qp_batch(B, n, n_eq, n_ineq, seed0=21, feasible=False, dtype=np.float32)
+    one = reluqpth.ReLU_QP()
+    one.setup(H, g, A, l, u, precision=torch.float32, device=DEV, kernel="resident", max_iter=500)
+    multi = reluqpth.ReLU_QP()
+    multi.setup(H, g, A, l, u, precision=torch.float32, devices=[0, 0, 0], kernel="resident", max_iter=500)
+    assert one.get_window()[0] == 5 and all(c.get_window()[0] == 5 for c in multi._shards.children)
+    r1, rm = one.solve(), multi.solve()
+    assert int((r1.info.rho_ind > 10).sum()) > 10                     # the windows moved
+    assert torch.equal(rm.x, r1.x) and torch.equal(rm.info.iter, r1.info.iter) and torch.equal(rm.info.rho_ind, r1.info.rho_ind)
+    r1, rm = one.solve(), multi.solve()                               # warm re-solve from the moved indices
+    assert torch.equal(rm.x, r1.x) and torch.equal(rm.info.iter, r1.info.iter)
 
 
 # ------------------------------------------------------------------- float64 resident kernel (the reference's precision)
