@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--kernel", default="auto", help="C-ABI kernel request (auto | generic | resident | wave | mfma)")
-    ap.add_argument("--tile", choices=["same", "f16"], default="same", help="K(rho) tile storage (BASELINE config 5: f16)")
+    ap.add_argument("--tile", choices=["same", "f16", "bf16"], default="same", help="f16: fp16 K(rho) tile of the resident kernel; "
+                    "bf16: shared-matrix batches on the 16-bit matrix pipe (two bf16 planes per operand; BASELINE config 5)")
     ap.add_argument("--low-memory", action="store_true", help="setup(low_memory=True): no packed copy of K(rho) (less workspace "
                     "and setup time, ~1 %% more solve time; not the default)")
     ap.add_argument("--workload", choices=["random_qp", "mpc", "c4"], default="random_qp",
@@ -275,7 +276,7 @@ def main():
         model = reluqpth.ReLU_QP()
         t0 = time.perf_counter()
         model.setup(Hd, gd, Ad, ld, ud, device=dev, precision=prec, eps_abs=args.eps_abs, warm_starting=False, kernel=args.kernel,
-                    iterate_dtype=torch.float16 if args.tile == "f16" else None, low_memory=args.low_memory,
+                    iterate_dtype={"f16": torch.float16, "bf16": torch.bfloat16}.get(args.tile), low_memory=args.low_memory,
                     full_ladder=args.full_ladder)
         torch.cuda.synchronize(dev)
         setup_times.append(time.perf_counter() - t0)

@@ -42,7 +42,16 @@ enum rqp_dtype { RQP_F32 = 0, RQP_F64 = 1 };
  * changes the convergence rate, never the fixed point; H, A and every residual stay in
  * dims.dtype.  RQP_TILE_F16 needs dims.dtype == RQP_F32.  The MFMA kernel (shared H, A)
  * takes the same fp16-rounded K into its float32 operand image.                        */
-enum rqp_tile_dtype { RQP_TILE_SAME = 0, RQP_TILE_F16 = 1 };
+enum rqp_tile_dtype {
+    RQP_TILE_SAME = 0,
+    RQP_TILE_F16 = 1,
+    /* Shared-(H, A) batches on the MFMA kernel: every matrix tile ([A; H'], A, K_j) and every vector operand is kept as two
+     * bf16 planes (hi + mid = 16 significant bits) and every product runs as three v_mfma_f32_16x16x32_bf16 with float32
+     * accumulation -- the 16-bit matrix pipe (16x the float32 MFMA rate); state, residuals and the checks stay float32.
+     * Same recurrence as the float32 kernel; operand error 2^-16 relative (stated tolerance: eps_abs >= 1e-5).  Needs
+     * dims.dtype == RQP_F32, shared_mats, n <= 80, m <= 320 (the MFMA kernel's shapes).                                     */
+    RQP_TILE_BF16 = 2
+};
 
 /* Solve-kernel request (rqp_dims.kernel).  AUTO = measured dispatch by size / batch /
  * sharing; an explicit kernel that cannot hold the problem makes rqp_setup return

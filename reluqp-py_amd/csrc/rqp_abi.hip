@@ -118,7 +118,7 @@ void free_ws(rqp_handle* h) {
 }
 
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    if (h->use_mfma && a.mode == 0) return rqp_launch_solve_mfma(h, a, s);
+    if (h->use_mfma && a.mode == 0) return h->mfma16 ? rqp_launch_solve_mfma16(h, a, s) : rqp_launch_solve_mfma(h, a, s);
     if (h->use_wave && a.mode == 0) return rqp_launch_solve_wave(h, a, s);
     if (h->resident) return rqp_launch_solve_res2(h, a, s);
     if (h->resident64) return rqp_launch_solve_res64(h, a, s);
@@ -191,8 +191,14 @@ int select_kernels(rqp_handle* h) {
         if (req != RQP_KERNEL_RESIDENT && !((req == RQP_KERNEL_MFMA || req == RQP_KERNEL_AUTO) && mfma_ok))
             return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320) or the MFMA kernel");
     }
-    h->resident = h->resident64 = h->use_wave = h->use_mfma = false;
+    h->resident = h->resident64 = h->use_wave = h->use_mfma = h->mfma16 = false;
     h->kernel_name = "generic";
+    if (h->dims.tile_dtype == RQP_TILE_BF16) {     // the bf16-plane tile exists in the MFMA kernel only: an explicit request for it
+        if (!rqp_mfma_fits(h) || (req != RQP_KERNEL_AUTO && req != RQP_KERNEL_MFMA))
+            return fail_unsupported(h, "tile_dtype = bf16 needs the MFMA kernel: float32, shared (H, A), n <= 80, m <= 320");
+        req = RQP_KERNEL_MFMA;
+        h->mfma16 = true;
+    }
     switch (req) {
         case RQP_KERNEL_GENERIC:
             break;
@@ -240,7 +246,7 @@ int select_kernels(rqp_handle* h) {
     h->windowed = !h->dims.shared_mats && h->nmat >= 32 && h->nrho > RQP_WINDOW && !(h->dims.flags & RQP_FLAG_FULL_LADDER) &&
                   !h->st.check_infeasibility && !h->use_mfma && !h->use_wave && !h->resident64;
     if (h->windowed) h->kwin = RQP_WINDOW;
-    if (h->use_mfma) h->kernel_name = "mfma";
+    if (h->use_mfma) h->kernel_name = h->mfma16 ? "mfma16" : "mfma";
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
     else if (h->resident64) h->kernel_name = "resident64";
@@ -269,11 +275,11 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
         if (!h->W1img) {
-            HIP_TRY(h, hipMalloc((void**)&h->W1img, rqp_mfma_img_elems(h) * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void**)&h->W1img, (h->mfma16 ? rqp_mfma16_img_elems(h) : rqp_mfma_img_elems(h)) * sizeof(float)));
             HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));
-            HIP_TRY(h, rqp_prepare_mfma(h));
+            HIP_TRY(h, h->mfma16 ? rqp_prepare_mfma16(h) : rqp_prepare_mfma(h));
         }
-        HIP_TRY(h, rqp_launch_pack_mfma(h, s));
+        HIP_TRY(h, h->mfma16 ? rqp_launch_pack_mfma16(h, s) : rqp_launch_pack_mfma(h, s));
     }
     return RQP_OK;
 }
@@ -309,7 +315,8 @@ int rqp_create(rqp_handle** out, const rqp_dims* dims, const rqp_settings* setti
     if (dims->n < 1 || dims->m < 1 || dims->batch < 1) return RQP_ERR_ARG;
     if (dims->dtype != RQP_F32 && dims->dtype != RQP_F64) return RQP_ERR_ARG;
     if (dims->kernel < RQP_KERNEL_AUTO || dims->kernel > RQP_KERNEL_MFMA) return RQP_ERR_ARG;
-    if (dims->tile_dtype != RQP_TILE_SAME && !(dims->tile_dtype == RQP_TILE_F16 && dims->dtype == RQP_F32)) return RQP_ERR_ARG;
+    if (dims->tile_dtype != RQP_TILE_SAME &&
+        !((dims->tile_dtype == RQP_TILE_F16 || dims->tile_dtype == RQP_TILE_BF16) && dims->dtype == RQP_F32)) return RQP_ERR_ARG;
     if (!settings_valid(*settings)) return RQP_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return RQP_ERR_HIP;
@@ -416,6 +423,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->cont_iter_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->cont_rho_d, (size_t)h->B * sizeof(double)));
         h->handoff_cols = 6;    // measured on the config-3 batch: 4.7 M QP/s without, 5.0 M at 2-4, 6.2 M at 6-10, 5.5 M at 12 (tools/)
+        if (const char* ho = getenv("RQP_TUNE_HANDOFF")) h->handoff_cols = atoi(ho);   // (tuning aid of tools/mfma16_check.py, not a dispatch input)
     }
     SetupArgs a = make_setup_args(h, H, g, A, l, u);
     HIP_TRY(h, rqp_launch_pack_vecs(h, a, s));

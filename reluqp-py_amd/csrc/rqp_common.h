@@ -54,6 +54,7 @@ struct rqp_handle {
     bool resident64 = false;      // rqp_res64.hip: the float64 resident kernel (n <= 104, m <= 320), all modes
     bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
+    bool mfma16 = false;          // ... on the bf16 matrix pipe (rqp_mfma16.hip, tile_dtype = RQP_TILE_BF16)
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
     int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
@@ -185,6 +186,11 @@ bool rqp_mfma_fits(const rqp_handle* h);
 size_t rqp_mfma_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+// the same kernel on the bf16 matrix pipe (rqp_mfma16.hip; rqp_dims.tile_dtype = RQP_TILE_BF16): same shapes as rqp_mfma_fits
+size_t rqp_mfma16_img_elems(const rqp_handle* h);
+hipError_t rqp_launch_pack_mfma16(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_prepare_mfma16(const rqp_handle* h);
+hipError_t rqp_launch_solve_mfma16(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 // Raise -- never lower -- the dynamic-LDS limit of kernel `fn` on the current device.  The attribute belongs to the FUNCTION, not
 // to a handle: a later, smaller handle must not shrink the limit an earlier, larger handle's launches rely on (process-wide

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RQP_LIB", os.path.join(_HERE, "lib", "librqp_hip.so"))
 
 RQP_F32, RQP_F64 = 0, 1
-RQP_TILE_SAME, RQP_TILE_F16 = 0, 1
+RQP_TILE_SAME, RQP_TILE_F16, RQP_TILE_BF16 = 0, 1, 2
 KERNELS = {"auto": 0, "generic": 1, "resident": 2, "resident2": 2, "wave": 3, "mfma": 4}     # enum rqp_kernel
 RQP_ERR_UNSUPPORTED = -5
 FLAG_LOW_MEMORY = 1          # rqp_dims.flags

@@ -152,7 +152,9 @@ class ReLU_QP(object):
         ``check_infeasibility``; ``kernel`` = "auto" | "generic" | "resident" | "wave" |
         "mfma" (C-ABI rqp_dims.kernel; an explicit kernel that cannot hold the problem raises);
         ``iterate_dtype=torch.float16`` keeps the K(rho) tile of the register-resident kernels in fp16
-        (BASELINE config 5; H, A, state and residuals stay float32).  ``devices=[0, 1, ...]`` splits a batch
+        (BASELINE config 5; H, A, state and residuals stay float32); ``iterate_dtype=torch.bfloat16`` runs a shared-(H, A) batch
+        on the bf16 matrix pipe (every matrix tile and vector operand as two bf16 planes, three 16-bit MFMAs per product,
+        float32 accumulation, state and residuals: rqp_abi.h RQP_TILE_BF16).  ``devices=[0, 1, ...]`` splits a batch
         contiguously over several GPUs inside this process (one handle and stream per device, results gathered on
         devices[0]; no collective -- reluqp/multidevice.py).  ``low_memory=True`` (rqp_dims.flags RQP_FLAG_LOW_MEMORY): the
         resident float32 kernel reads K(rho) from the factor kernel's table instead of a packed copy -- 43 % less workspace,
@@ -201,11 +203,11 @@ class ReLU_QP(object):
                                  check_infeasibility=check_infeasibility)
         if kernel not in _cabi.KERNELS:
             raise ValueError("kernel must be one of %s" % sorted(_cabi.KERNELS))
-        if iterate_dtype not in (None, precision, torch.float16):
-            raise ValueError("iterate_dtype must be None, the working precision or torch.float16")
-        if iterate_dtype == torch.float16 and precision != torch.float32:
-            raise ValueError("iterate_dtype=torch.float16 needs precision=torch.float32")
-        tile = _cabi.RQP_TILE_F16 if iterate_dtype == torch.float16 else _cabi.RQP_TILE_SAME
+        if iterate_dtype not in (None, precision, torch.float16, torch.bfloat16):
+            raise ValueError("iterate_dtype must be None, the working precision, torch.float16 or torch.bfloat16")
+        if iterate_dtype in (torch.float16, torch.bfloat16) and precision != torch.float32:
+            raise ValueError("iterate_dtype=torch.float16 / torch.bfloat16 needs precision=torch.float32")
+        tile = {torch.float16: _cabi.RQP_TILE_F16, torch.bfloat16: _cabi.RQP_TILE_BF16}.get(iterate_dtype, _cabi.RQP_TILE_SAME)
         with torch.cuda.device(device):
             start, end = self._events()
             start.record()
