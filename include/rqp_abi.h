@@ -131,8 +131,15 @@ typedef struct rqp_settings {
     double eps_prim_inf;           /* 1e-4  certificate tolerances (check_infeasibility)                    */
     double eps_dual_inf;           /* 1e-4  */
     int32_t scaling;               /* 0: none (the reference's `scaling` is an unused TODO, reluqpth.py:105);
-                                      k > 0: k Ruiz equilibration passes at setup, results un-scaled          */
-    int32_t check_infeasibility;   /* 0.  1: test the OSQP certificates at every check                       */
+                                      k > 0: k Ruiz equilibration passes at setup; results, residuals and the
+                                      termination test in the caller's (un-scaled) units                       */
+    int32_t check_infeasibility;   /* 0.  1: OSQP's primal / dual infeasibility certificates.  The streaming kernel
+                                      (RQP_KERNEL_GENERIC) tests them at every check and exits at the first one that
+                                      holds; the register-resident / wavefront / MFMA kernels keep their loops
+                                      untouched: an instance that spends max_iter (or ends nan_detected) is examined
+                                      once, after the launch, and labelled -- it has then run its whole budget.
+                                      AUTO therefore dispatches a handle with this option to the streaming kernel;
+                                      the other kernels take it on explicit request only.                          */
 } rqp_settings;
 
 /* Per-instance results of one solve (classes.py:67-88), struct of DEVICE arrays,

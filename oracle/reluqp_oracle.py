@@ -233,26 +233,33 @@ def _tmax(a, b):
     return a if a >= b else b
 
 
-def residual_scales(H, A, g, x, z, lam):
+def residual_scales(H, A, g, x, z, lam, wE=None, wD=None):
     """(max(|Ax|,|z|), max(|Hx|,|A'lam|,|g|)) in inf-norms: the denominators of reluqpth.py:315-316, reused by the
-    build's eps_rel extension as the scales of the two residuals."""
+    build's eps_rel extension as the scales of the two residuals.  wE / wD: see compute_residuals."""
     T = x.dtype.type
-    sp = _tmax(T(_inf_norm(A @ x)), T(_inf_norm(z)))
-    sd = _tmax(_tmax(T(_inf_norm(H @ x)), T(_inf_norm(A.T @ lam))), T(_inf_norm(g)))
+    wE = T(1) if wE is None else wE.astype(x.dtype)
+    wD = T(1) if wD is None else wD.astype(x.dtype)
+    sp = _tmax(T(_inf_norm((A @ x) * wE)), T(_inf_norm(z * wE)))
+    sd = _tmax(_tmax(T(_inf_norm((H @ x) * wD)), T(_inf_norm((A.T @ lam) * wD))), T(_inf_norm(g * wD)))
     return sp, sd
 
 
-def compute_residuals(H, A, g, x, z, lam, rho, rho_min, rho_max):
-    """reluqpth.py:307-318.  Returns (primal_res, dual_res, rho_estimate)."""
+def compute_residuals(H, A, g, x, z, lam, rho, rho_min, rho_max, wE=None, wD=None):
+    """reluqpth.py:307-318.  Returns (primal_res, dual_res, rho_estimate).
+    Build extension (Ruiz scaling): wE = 1 / E (rows) and wD = 1 / (c D) (columns) take every term back to the caller's
+    space before its inf-norm (H, A, g, x, z, lam are the scaled quantities): "solved" then certifies the tolerances in
+    the caller's units (OSQP's scaled_termination = 0).  Statement of the weighted maxima of the HIP kernels."""
     T = x.dtype.type
+    wE = T(1) if wE is None else wE.astype(x.dtype)
+    wD = T(1) if wD is None else wD.astype(x.dtype)
     t1 = A @ x                                             # :309
     t2 = H @ x                                             # :310
     t3 = A.T @ lam                                         # :311
-    pri = T(_inf_norm(t1 - z))                             # :313
-    dua = T(_inf_norm(t2 + t3 + g))                        # :314
+    pri = T(_inf_norm(np.abs(t1 - z) * wE))                # :313
+    dua = T(_inf_norm(np.abs(t2 + t3 + g) * wD))           # :314
     with np.errstate(invalid="ignore", divide="ignore"):
-        num = pri / _tmax(T(_inf_norm(t1)), T(_inf_norm(z)))                          # :315
-        den = dua / _tmax(_tmax(T(_inf_norm(t2)), T(_inf_norm(t3))), T(_inf_norm(g)))  # :316
+        num = pri / _tmax(T(_inf_norm(t1 * wE)), T(_inf_norm(z * wE)))                          # :315
+        den = dua / _tmax(_tmax(T(_inf_norm(t2 * wD)), T(_inf_norm(t3 * wD))), T(_inf_norm(g * wD)))  # :316
         est = T(rho) * np.sqrt(num / den)                  # :317
     # torch.clamp keeps NaN (Q17)
     if est < rho_min:
@@ -529,7 +536,7 @@ class OracleQP:
                 s = self.output
                 self.x, self.z, self.lam = s[:n], s[n:n + m], s[n + m:]      # :219
                 pri, dua, rho = compute_residuals(self.H, self.A, self.g, self.x, self.z, self.lam,
-                                                  rho, st.rho_min, st.rho_max)   # :220
+                                                  rho, st.rho_min, st.rho_max, *self._unscale_weights())   # :220
                 self.trace.append((float(pri), float(dua), float(rho), self.rho_ind))
                 if rho > self.rhos[self.rho_ind] * tol and self.rho_ind < nrho - 1:   # :223
                     self.rho_ind += 1
@@ -539,7 +546,7 @@ class OracleQP:
                     print('Iter: {}, rho: {:.2e}, res_p: {:.2e}, res_d: {:.2e}'.format(k, rho, pri, dua))
                 tp, td = thr_p, thr_d
                 if st.eps_rel > 0:                         # build extension (8(f)-3): OSQP-style relative term
-                    sp, sd = residual_scales(self.H, self.A, self.g, self.x, self.z, self.lam)
+                    sp, sd = residual_scales(self.H, self.A, self.g, self.x, self.z, self.lam, *self._unscale_weights())
                     tp, td = thr_p + st.eps_rel * sp, thr_d + st.eps_rel * sd
                 if pri < tp and dua < td:                  # :233
                     self._update_results(k, STATUS_SOLVED, pri, dua, rho, t0)
@@ -555,12 +562,20 @@ class OracleQP:
             s = self.output
             self.x, self.z, self.lam = s[:n], s[n:n + m], s[n + m:]
         pri, dua, rho = compute_residuals(self.H, self.A, self.g, self.x, self.z, self.lam,
-                                          rho, st.rho_min, st.rho_max)           # :243
+                                          rho, st.rho_min, st.rho_max, *self._unscale_weights())           # :243
         status = STATUS_MAX_ITER
         if not self.quirks and (np.isnan(pri) or np.isnan(dua)):
             status = STATUS_NAN                            # build extension: the reference reports max_iters_reached (Q17)
         self._update_results(st.max_iter, status, pri, dua, rho, t0)
         return self.results
+
+    def _unscale_weights(self):
+        """(1 / E, 1 / (c D)) with Ruiz scaling, else (None, None): compute_residuals."""
+        sc = getattr(self, "_sc", None)
+        if sc is None:
+            return None, None
+        D, E, c = sc
+        return 1.0 / E, 1.0 / (c * D)
 
     # a9 ------------------------------------------------------ update_results
     def _update_results(self, it, status, pri, dua, rho, t0):
@@ -571,7 +586,7 @@ class OracleQP:
         self.results.lam = self.lam.copy()
         self.info.obj_val = compute_J(self.H, self.g, self.x)
         sc = getattr(self, "_sc", None)
-        if sc is not None:                                 # scaled space -> caller space (residuals stay scaled)
+        if sc is not None:                                 # scaled space -> caller space (the residuals already are: compute_residuals)
             D, E, c = sc
             self.results.x = self.results.x * D
             self.results.z = self.results.z / E

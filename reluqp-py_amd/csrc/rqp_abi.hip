@@ -160,6 +160,7 @@ SolveArgs make_solve_args(const rqp_handle* h) {
     }
     a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
     a.rhos = h->rhos_d;
+    if (h->st.scaling > 0) { a.scD = h->Dsc; a.scE = h->Esc; a.scC = h->csc; }
     a.x = h->x; a.z = h->z; a.lam = h->lam; a.rho_ind = h->rho_ind;
     return a;
 }
@@ -223,6 +224,10 @@ int select_kernels(rqp_handle* h) {
             // (minus skipped zero groups); on n=30, m=60 the one-wavefront kernel is 3-4x faster, on n=20, m=80 the mid
             // resident tile is on par (measured)
             const bool mfma_pays = h->B >= 2048 && (h->n > 56 || h->m > 128);
+            // check_infeasibility: only the streaming kernel tests the certificates at every check (an infeasible instance
+            // leaves at the first check where one holds, like the oracle; the other kernels would run it to max_iter first)
+            if (h->st.check_infeasibility)
+                break;
             if (rqp_mfma_fits(h) && mfma_pays)
                 h->use_mfma = true;
             else if (rqp_wave_fits(h))       // small problems: one wavefront per instance

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
     }
 
     if (a.mode == 3) {                       // certificate pass behind another solve kernel (rqp_solve): only the instances that
-        const bool todo = a.info.status[b] == RQP_STATUS_MAX_ITER;      // spent their iterations are examined; the state the
+        const bool todo = a.info.status[b] == RQP_STATUS_MAX_ITER || a.info.status[b] == RQP_STATUS_NAN;   // spent their iterations are examined; the state the
         if (!todo) {                                                    // solve kernel was asked to keep is cleared here
             if (!a.warm_starting) {
                 for (int i = tid; i < n; i += RQP_NT) a.x[(size_t)b * n + i] = 0.0;
@@ -277,17 +277,24 @@ __global__ void __launch_bounds__(RQP_NT) k_admm_generic(SolveArgs a) {
         T v[7];
 #pragma unroll
         for (int e = 0; e < 7; ++e) v[e] = T(0);
+        // (Ruiz scaling: every term goes back to the caller's space before its norm -- SolveArgs.scE)
+        const size_t smat = (a.sA == 0) ? 0 : (size_t)b;
+        const double* sE = a.scE ? a.scE + smat * m : nullptr;
+        const double* sD = a.scD ? a.scD + smat * n : nullptr;
+        const double sc = a.scC ? a.scC[smat] : 1.0;
         for (int i = tid; i < m; i += RQP_NT) {
+            const T we = sE ? (T)(1.0 / sE[i]) : T(1);
             const T t1 = (T)zts[i], zi = (T)zs[i];
-            v[0] = tmax(v[0], (T)fabs((T)(zts[i] - zs[i])));       // |A x - z|
-            v[1] = tmax(v[1], (T)fabs(t1));
-            v[2] = tmax(v[2], (T)fabs(zi));
+            v[0] = tmax(v[0], (T)fabs((T)(zts[i] - zs[i])) * we);  // |A x - z|
+            v[1] = tmax(v[1], (T)fabs(t1) * we);
+            v[2] = tmax(v[2], (T)fabs(zi) * we);
         }
         for (int i = tid; i < n; i += RQP_NT) {
-            v[3] = tmax(v[3], (T)fabs(hx[i] + vn[i] + gT[i]));     // |H x + A' lam + g|
-            v[4] = tmax(v[4], (T)fabs(hx[i]));
-            v[5] = tmax(v[5], (T)fabs(vn[i]));
-            v[6] = tmax(v[6], (T)fabs(gT[i]));
+            const T wd = sD ? (T)(1.0 / (sc * sD[i])) : T(1);
+            v[3] = tmax(v[3], (T)fabs(hx[i] + vn[i] + gT[i]) * wd);   // |H x + A' lam + g|
+            v[4] = tmax(v[4], (T)fabs(hx[i]) * wd);
+            v[5] = tmax(v[5], (T)fabs(vn[i]) * wd);
+            v[6] = tmax(v[6], (T)fabs(gT[i]) * wd);
         }
         block_max<T, 7>(v, red);
         o_pri = v[0];

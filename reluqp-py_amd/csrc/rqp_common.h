@@ -100,6 +100,11 @@ struct SolveArgs {
                               //    generic kernel in mode 3 afterwards on the instances that spent their iterations)
     int keep_state;           // 1: persist the state even when warm_starting = 0 (a mode-3 pass follows and clears it)
     double eps_rel;           // 0: absolute test only (reluqpth.py:233); > 0: thresholds grow by eps_rel * the residual's scale
+    // Ruiz scaling (settings.scaling > 0; NULL otherwise): D [nmat][n], E [nmat][m], c [nmat].  The kernels iterate in the scaled
+    // space; every quantity of compute_residuals is taken back to the CALLER's space before its inf-norm -- row i of the primal
+    // side times 1 / E_i, column j of the dual side times 1 / (c D_j) -- so that "solved" certifies eps_abs / eps_rel in the
+    // caller's units (OSQP's default, scaled_termination = 0) and pri_res / dua_res are reported there.
+    const double *scD, *scE, *scC;
     const void *Ht, *A, *At, *K;
     size_t sH, sA, sAt, sK;   // per-instance strides in elements (0 when shared)
     const void *g, *l, *u, *c;

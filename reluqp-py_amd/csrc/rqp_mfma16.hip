@@ -655,10 +655,13 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma16(SolveArgs a, const unsig
                 for (int tl = 0; tl < MBW; ++tl) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        // (Ruiz scaling: caller-space norms, SolveArgs.scE; shared matrices: one set of factors)
+                        const int row = 16 * C::tile_of(wave_u, tl) + 4 * (lp >> 4) + r;
+                        const float we = (a.scE && row < m) ? (float)(1.0 / a.scE[row]) : 1.f;
                         const float zlo = ZL[(tl * NT + tid) * 4 + r];
-                        v0 = nanmaxf16(v0, fabsf((zh[tl][r] - zz[tl][r]) + zlo));
-                        v1 = nanmaxf16(v1, fabsf(zh[tl][r] + zlo));
-                        v2 = nanmaxf16(v2, fabsf(zz[tl][r]));
+                        v0 = nanmaxf16(v0, fabsf((zh[tl][r] - zz[tl][r]) + zlo) * we);
+                        v1 = nanmaxf16(v1, fabsf(zh[tl][r] + zlo) * we);
+                        v2 = nanmaxf16(v2, fabsf(zz[tl][r]) * we);
                     }
                     put_rows(lp, C::tile_of(wave_u, tl), lm[tl][0], lm[tl][1], lm[tl][2], lm[tl][3]);
                 }
@@ -702,10 +705,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma16(SolveArgs a, const unsig
 #pragma unroll
                 for (int w = 0; w < NW; ++w) t2 += part[w * NP * 16 + xb3 + 256 * e];
                 const float ge = GV[row * 16 + cj], t3 = T3[e * NT + tid];
-                w3 = nanmaxf16(w3, fabsf(t2 + t3 + ge));
-                w4 = nanmaxf16(w4, fabsf(t2));
-                w5 = nanmaxf16(w5, fabsf(t3));
-                w6 = nanmaxf16(w6, fabsf(ge));
+                const float wd = (a.scD && row < n) ? (float)(1.0 / (a.scC[0] * a.scD[row])) : 1.f;
+                w3 = nanmaxf16(w3, fabsf(t2 + t3 + ge) * wd);
+                w4 = nanmaxf16(w4, fabsf(t2) * wd);
+                w5 = nanmaxf16(w5, fabsf(t3) * wd);
+                w6 = nanmaxf16(w6, fabsf(ge) * wd);
                 jp += xr[e] * (0.5f * t2 + ge);                      // compute_J :320-322
             }
             rr[(rg * 16 + cj) * 8 + 3] = w3;

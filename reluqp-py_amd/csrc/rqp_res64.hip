@@ -287,23 +287,26 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     // updates stat[0..4] = pri, dua, rho estimate (carried, Q4), scale of pri, scale of dua; ends with a barrier
     auto residuals = [&]() {
         double v[7] = {0, 0, 0, 0, 0, 0, 0};
+        const size_t smat = (a.sA == 0) ? 0 : (size_t)b;              // (Ruiz scaling: caller-space norms, SolveArgs.scE)
         if (rown) {
+            const double we = (a.scE && rin) ? 1.0 / a.scE[smat * m + tid] : 1.0;
             nuL[tid] = lam;
-            v[0] = fabs(zt - z);
-            v[1] = fabs(zt);
-            v[2] = fabs(z);
+            v[0] = fabs(zt - z) * we;
+            v[1] = fabs(zt) * we;
+            v[2] = fabs(z) * we;
         }
         __syncthreads();
         const double t3 = prod_At(true, false, nuL);                  // A' lam
         __syncthreads();                                              // (slab reuse)
         const double t2 = prod_At(false, true, nuL);                  // H x
         if (xown) {
+            const double wd = (a.scD && xin) ? 1.0 / (a.scC[smat] * a.scD[smat * n + xcol]) : 1.0;
             const double gx = gL[xcol];
             hxL[xcol] = t2;
-            v[3] = fabs(t2 + t3 + gx);
-            v[4] = fabs(t2);
-            v[5] = fabs(t3);
-            v[6] = fabs(gx);
+            v[3] = fabs(t2 + t3 + gx) * wd;
+            v[4] = fabs(t2) * wd;
+            v[5] = fabs(t3) * wd;
+            v[6] = fabs(gx) * wd;
         }
         // 7 maxima over the workgroup, NaN-propagating like torch.max / norm(inf): NaN flags travel as a bit mask, the values
         // through v_max_f64 (which skips NaN).  Wave level in registers; the 8 waves meet in LDS and wave 0 finishes:

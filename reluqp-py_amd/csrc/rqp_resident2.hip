@@ -569,11 +569,16 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         float v[7];
 #pragma unroll
         for (int e = 0; e < 7; ++e) v[e] = 0.f;
-        for (int i = tid; i < M; i += NT) {
+        // (Ruiz scaling: every term goes back to the caller's space before its norm -- SolveArgs.scE; the weights are read
+        //  here, at the check, from an opaque copy of tid: no registers of the solve loop)
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));
+        for (int i = tid_w; i < M; i += NT) {
+            const float we = (a.scE && i < m) ? (float)(1.0 / a.scE[mat * m + i]) : 1.f;
             nu[i] = (float)lam64[i];
-            v[0] = tmax2(v[0], fabsf((float)(zt64[i] - z64[i])));
-            v[1] = tmax2(v[1], fabsf((float)zt64[i]));
-            v[2] = tmax2(v[2], fabsf((float)z64[i]));
+            v[0] = tmax2(v[0], fabsf((float)(zt64[i] - z64[i])) * we);
+            v[1] = tmax2(v[1], fabsf((float)zt64[i]) * we);
+            v[2] = tmax2(v[2], fabsf((float)z64[i]) * we);
         }
         __syncthreads();
         if (tid < ND && (tid % SW) >= CW) {                              // padding slots: exact zeros
@@ -584,11 +589,16 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
         prod_At(NO, YES, nu, hx, false);                               // t2 = H x
         __syncthreads();
         if (tid < ND) {                                                 // padding slots hold zeros
+            float wd = 1.f;
+            if (a.scD) {
+                const int col = CW * (tid_w / SW) + (tid_w % SW);
+                if ((tid_w % SW) < CW && col < n) wd = (float)(1.0 / (a.scC[mat] * a.scD[mat * n + col]));
+            }
             const float t3 = dxv[tid];
-            v[3] = fabsf(hx[tid] + t3 + gT[tid]);
-            v[4] = fabsf(hx[tid]);
-            v[5] = fabsf(t3);
-            v[6] = fabsf(gT[tid]);
+            v[3] = fabsf(hx[tid] + t3 + gT[tid]) * wd;
+            v[4] = fabsf(hx[tid]) * wd;
+            v[5] = fabsf(t3) * wd;
+            v[6] = fabsf(gT[tid]) * wd;
         }
         // wave max of 7 values + NaN mask (torch max/norm propagate NaN): v_max (IEEE maxNum) on DPP / permlane swaps
         unsigned nanm = 0;

@@ -9,8 +9,11 @@
 // (H, A) has ONE scaling for the whole batch).  The ADMM kernels then solve, unchanged,
 //     min 1/2 xb' (c Hbar) xb + (c D g)' xb   s.t.  E l <= Abar xb <= E u,        x = D xb,  z = E^-1 zb,  lam = E lamb / c
 // and every boundary of the C ABI converts: inputs (g, l, u, warm starts) are scaled on the way in, outputs (x, z, lam,
-// obj) un-scaled on the way out.  Residuals and the termination test live in the scaled space (OSQP's
-// scaled_termination); rqp_get_K / rqp_iterate / rqp_compute_residuals expose that space as it is.
+// obj) un-scaled on the way out.  compute_residuals takes every term back to the caller's space before its inf-norm (row i of
+// the primal side x 1 / E_i, column j of the dual side x 1 / (c D_j): SolveArgs.scE, every ADMM kernel), so the termination
+// test certifies eps_abs / eps_rel in the caller's units and pri_res / dua_res are reported there (OSQP's default,
+// scaled_termination = 0); the rho estimate is formed from the same caller-space ratios.  rqp_get_K / rqp_iterate expose
+// the scaled space as it is.
 #include "rqp_common.h"
 
 namespace {

@@ -218,17 +218,20 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     T scl_p = (T)0, scl_d = (T)0;                                       // residual scales of the last check (eps_rel)
     auto residuals = [&](T rho_carry, T& o_pri, T& o_dua) -> T {
         T w0 = (T)0, w1 = (T)0, w2 = (T)0;
+        const size_t smat = (a.sA == 0) ? 0 : (size_t)b;                // (Ruiz scaling: caller-space norms, SolveArgs.scE)
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
+            const T we = (a.scE && r0 + 64 * q < m) ? (T)(1.0 / a.scE[smat * m + r0 + 64 * q]) : (T)1;
             nuL[r0 + 64 * q] = (T)lam[q];
-            w0 = wtmax(w0, (T)fabs((T)(zt[q] - z[q])));
-            w1 = wtmax(w1, (T)fabs((T)zt[q]));
-            w2 = wtmax(w2, (T)fabs((T)z[q]));
+            w0 = wtmax(w0, (T)fabs((T)(zt[q] - z[q])) * we);
+            w1 = wtmax(w1, (T)fabs((T)zt[q]) * we);
+            w2 = wtmax(w2, (T)fabs((T)z[q]) * we);
         }
         handoff();
         const T t3 = all_parts(fold(at_times(zero2)));                  // A' lam
         hx = all_parts(fold(h_times(zero2)));                           // H x
-        T v[7] = {w0, w1, w2, (T)fabs(hx + t3 + gc), (T)fabs(hx), (T)fabs(t3), (T)fabs(gc)};
+        const T wd = (a.scD && cok) ? (T)(1.0 / (a.scC[smat] * a.scD[smat * n + c])) : (T)1;
+        T v[7] = {w0, w1, w2, (T)fabs(hx + t3 + gc) * wd, (T)fabs(hx) * wd, (T)fabs(t3) * wd, (T)fabs(gc) * wd};
         inst_tmax7(v);
         const T v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4], v5 = v[5], v6 = v[6];
         if constexpr (NWV > 1) __syncthreads();                         // redL is reused by the next check

@@ -148,8 +148,10 @@ class ReLU_QP(object):
         (reference reluqpth.py:102-157).  g, l, u may carry a leading batch
         dimension; H and A then either carry it too or are shared.
 
-        Extensions beyond the reference (all default to its behaviour): ``eps_rel``, ``scaling``,
-        ``check_infeasibility``; ``kernel`` = "auto" | "generic" | "resident" | "wave" |
+        Extensions beyond the reference (all default to its behaviour): ``eps_rel``, ``scaling`` (k Ruiz passes; results,
+        residuals and the termination test in the caller's units), ``check_infeasibility`` (OSQP's
+        certificates at every check on the streaming kernel, which ``kernel="auto"`` then picks; an explicitly requested
+        resident / wave / mfma kernel labels an infeasible instance only after it has spent ``max_iter``); ``kernel`` = "auto" | "generic" | "resident" | "wave" |
         "mfma" (C-ABI rqp_dims.kernel; an explicit kernel that cannot hold the problem raises);
         ``iterate_dtype=torch.float16`` keeps the K(rho) tile of the register-resident kernels in fp16
         (BASELINE config 5; H, A, state and residuals stay float32); ``iterate_dtype=torch.bfloat16`` runs a shared-(H, A) batch

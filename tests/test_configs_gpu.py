@@ -144,14 +144,15 @@ def _oracle_closed_loop(ctl, x0, steps):
 
 
 @pytest.mark.parametrize("B,tile,kernel", [(4096, None, "mfma"), (64, None, "resident2"), (64, torch.float16, "resident2"),
-                                           (4096, torch.float16, "mfma")])
+                                           (4096, torch.float16, "mfma"), (4096, torch.bfloat16, "mfma16")])
 def test_c5_closed_loop_1000_steps_vs_oracle(B, tile, kernel):
     """1000 control steps, update(g,l,u) from the current state + warm-started solve() per step (the path of
     reluqpth.py:159-183 + :201-249) at the C3 shape; instances 0..7 against the oracle closed loop.  Batch 4096 runs on
     the MFMA kernel, the small batch ("1 instance stream or small batch") on the register-resident tile.
     tile=float16: BASELINE config 5's "fp16 iterate / fp32 residual" mode -- the K(rho) tile in fp16 (it only
     preconditions dx = -K d), H, A, the state and every residual in float32/float64; at batch 4096 the MFMA
-    kernel takes the same fp16-rounded K into its operand image, so the mode keeps the large-batch kernel."""
+    kernel takes the same fp16-rounded K into its operand image, so the mode keeps the large-batch kernel.
+    tile=bfloat16: the batch on the 16-bit matrix pipe (k_admm_mfma16: two bf16 planes per operand, tests/test_mfma16_gpu.py)."""
     import reluqp.reluqpth as reluqpth
     NB, STEPS = 8, 1000
     ctl, x0 = _c3(B, seed=11)
