@@ -26,7 +26,7 @@ namespace {
 
 constexpr int R64_NT = 512, R64_NW = 8, R64_CW = 13, R64_RL = 5, R64_N = 104, R64_M = 320, R64_KC = 26;
 constexpr int R64_PS = 10;                         // doubles per row of the A dx partials: 8 waves + 2 (16-byte rows, conflict-free b128 reads)
-constexpr int R64_RS = 68;                         // stride (doubles) of a column's 64 lane partials in the reduce slab: = 4 (mod 32), see the slab sum
+constexpr int R64_RS = 66;                         // stride (doubles) of a column's 64 lane partials in the reduce slab
 constexpr size_t r64_lds_doubles() {
     return (size_t)R64_N * R64_N                   // Hs [col][row]
            + (size_t)R64_NW * R64_CW * R64_RS      // reduce slabs; the A dx partials part[8][320] alias their start
@@ -219,16 +219,16 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         __builtin_amdgcn_wave_barrier();
         double s = 0.0;
         if (rr < CW) {
-            // lane (column rr, quarter cc) adds the partials 4 k + cc, k = 0..15: with the stride RS = 4 (mod 32) the 32 lanes of a
-            // half-wave (rr = 0..7 x cc = 0..3) read 32 DISTINCT bank pairs at every k (address mod 32 = 4 rr + cc + 4 k).  The
-            // contiguous split (16 cc + k, stride 66) put lanes cc / cc + 2 and rr / rr + 8 on the same banks: 20 % of this
-            // kernel's LDS cycles were conflict replays (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r2_resident64).
-            const double* src = sl + rr * RS + cc;
+            // (Round 3 tried the two conflict-free forms of this sum -- lane (column, quarter q) adding the partials 4 k + q with
+            //  slab stride 68, or the pairs (8 k + 2 q, + 1) by ds_read_b128 with stride 72: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+            //  fell from 0.20 to 0.10, but the kernel was 5 % / 3.5 % SLOWER on the same box (tools/ab_bench.sh: 6.29 -> 6.51 ms):
+            //  the segment is bound by the latency of its dependent LDS round trips, not by replay cycles.  Contiguous form kept.)
+            const double* src = sl + rr * RS + 16 * cc;
             double s0 = 0.0, s1 = 0.0;                                // two chains of 8
 #pragma unroll
             for (int k = 0; k < 16; k += 2) {
-                s0 += src[4 * k];
-                s1 += src[4 * k + 4];
+                s0 += src[k];
+                s1 += src[k + 1];
             }
             s = s0 + s1;
         }

@@ -12,7 +12,7 @@ for args in "$@"; do
     for v in old new; do
       cp .ab/lib_$v.so $L
       printf "%s [%s] %s: " "$v" "$args" "$rep"
-      timeout -k 10 100 python bench.py --cpu-seconds 0 --steps 30 --warmup 3 $args 2>&1 | tail -1 | grep -o "\"kernel_ms\": [0-9.]*" | tr '\n' ' '
+      timeout -k 10 150 python bench.py --cpu-seconds 0 --steps 20 --warmup 3 --fresh-batches 2 $args 2>&1 | tail -1 | grep -o "\"kernel_ms\": [0-9.]*" | tr '\n' ' '
       echo
     done
   done
