@@ -25,7 +25,7 @@ Rank 0 prints ONE JSON line.  `value` = all QPs solved by all ranks / max-over-r
 `roofline` prices the ADMM kernel against the roof that BINDS it:
   resident2 / wave : "valu" -- matrices live in registers, HBM is out of the picture; algorithmic flops
                      (2n^2 + 4mn per instance-iteration) / kernel time / 157.3 TF fp32 vector peak
-  mfma             : "mfma" -- the same flops against the 157.3 TF fp32 matrix peak
+  mfma             : "mfma" -- the same flops against the 157.3 TF fp32 matrix peak (mfma16: against the 2.5 PF dense bf16 peak)
   generic          : "hbm"  -- algorithmic bytes 4(n^2 + mn) per instance-iteration / kernel time / 8 TB/s
 `hbm_algorithmic_x` keeps the streaming-model GB/s figure (may exceed the HBM peak for the resident kernels: the
 matrices are not re-read).  `cpu_baseline` times the oracle on the host cores in child processes started BEFORE this
@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (f32 in / f32 acc) dense peak
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: vector fp64 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the sparsity figure is twice that: never priced against)
 
 
 def parse():
@@ -193,9 +194,10 @@ def pmc_traffic(kernel, args, kern_s):
     (MI355X_MICROARCH.md).  None when no profile of this kernel on this workload is committed."""
     sig = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision, args.tile)
     table = {
-        ("resident2", ("random_qp", 4096, 100, 25, 275, "f32", "same")): "r2_resident2/pmc.json",
-        ("mfma", ("mpc", 4096, 100, 25, 275, "f32", "same")): "r2_mfma/pmc.json",
-        ("wave", ("c4", 8192, 32, 8, 56, "f32", "same")): "r2_wave/pmc.json",
+        ("resident2", ("random_qp", 4096, 100, 25, 275, "f32", "same")): "r3_resident2/pmc.json",
+        ("mfma", ("mpc", 4096, 100, 25, 275, "f32", "same")): "r3_mfma/pmc.json",
+        ("mfma16", ("mpc", 4096, 100, 25, 275, "f32", "bf16")): "r3_mfma16/pmc.json",
+        ("wave", ("c4", 8192, 32, 8, 56, "f32", "same")): "r3_wave/pmc.json",
     }
     name = table.get((kernel, sig))
     if name is None:
@@ -362,6 +364,14 @@ def main():
             roof = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                     "note": "dense algorithmic flops 2n^2+4mn per instance-iteration; the kernel skips all-zero operand groups of the "
                             "block-triangular MPC matrices, so it executes fewer"}
+        elif kernel == "mfma16":
+            # three bf16 MFMAs per product term pair: the executed matrix flops are 3x the algorithmic ones; priced in ALGORITHMIC
+            # flops against the dense bf16 matrix peak (the kernel is bound by its VALU / LDS phases, not by this roof)
+            roof = {"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS,
+                    "note": "algorithmic flops 2n^2+4mn per instance-iteration against the dense bf16 MFMA peak; operands are two bf16 "
+                            "planes and a product is three v_mfma_f32_16x16x32_bf16 (executed matrix flops = 3x + padding); the "
+                            "kernel's time is VALU / LDS latency of its row and column phases (DESIGN.md section 4)",
+                    "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
         elif kernel == "generic":
             roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS}
         else:
