@@ -95,9 +95,11 @@ __global__ void __launch_bounds__(256) k_ruiz(int n, int m, int ldn, int ldm, in
         const int i = e / n, j = e % n;
         H[(size_t)i * ldn + j] = (T)((double)H[(size_t)i * ldn + j] * c);
     }
-    for (int e = tid; e < n * ldm; e += 256) {
-        const int r = e / ldm, cc = e % ldm;
-        Atm[e] = (cc < m) ? Am[(size_t)cc * ldn + r] : T(0);
+    if (At) {                                      // (no transposed copy on handles whose kernels never read it: rqp_setup)
+        for (int e = tid; e < n * ldm; e += 256) {
+            const int r = e / ldm, cc = e % ldm;
+            Atm[e] = (cc < m) ? Am[(size_t)cc * ldn + r] : T(0);
+        }
     }
 }
 

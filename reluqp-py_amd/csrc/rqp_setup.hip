@@ -43,9 +43,11 @@ __global__ void k_pack_mats(SetupArgs a) {
             int r = i / a.ldn, c = i % a.ldn;
             Ap[i] = (c < a.n) ? A[(size_t)r * a.n + c] : T(0);
         }
-        for (int i = tid; i < a.n * a.ldm; i += nth) {
-            int r = i / a.ldm, c = i % a.ldm;
-            At[i] = (c < a.m) ? A[(size_t)c * a.n + r] : T(0);
+        if (a.At) {                                // (NULL: no kernel of this handle reads the transposed copy, rqp_setup)
+            for (int i = tid; i < a.n * a.ldm; i += nth) {
+                int r = i / a.ldm, c = i % a.ldm;
+                At[i] = (c < a.m) ? A[(size_t)c * a.n + r] : T(0);
+            }
         }
     }
 }
