@@ -55,6 +55,7 @@ struct rqp_handle {
     bool use_wave = false;        // rqp_wave.hip: one wavefront per instance (n <= 32, m <= 64), solve() only
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
     bool mfma16 = false;          // ... on the bf16 matrix pipe (rqp_mfma16.hip, tile_dtype = RQP_TILE_BF16)
+    bool mfmal = false;           // ... large / sparse problems, operands streamed from L2 (rqp_mfmal.hip: n <= 320, m <= 640)
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
     int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
@@ -191,6 +192,12 @@ bool rqp_mfma_fits(const rqp_handle* h);
 size_t rqp_mfma_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfma(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+// large / sparse shared-matrix problems (rqp_mfmal.hip): operands streamed from L2, non-zero k-step lists
+bool rqp_mfmal_fits(const rqp_handle* h);
+size_t rqp_mfmal_img_elems(const rqp_handle* h);
+hipError_t rqp_launch_pack_mfmal(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_prepare_mfmal(const rqp_handle* h);
+hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 // the same kernel on the bf16 matrix pipe (rqp_mfma16.hip; rqp_dims.tile_dtype = RQP_TILE_BF16): same shapes as rqp_mfma_fits
 size_t rqp_mfma16_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfma16(const rqp_handle* h, hipStream_t s);
