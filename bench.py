@@ -76,6 +76,9 @@ def parse():
                     help="random_qp: the headline metric's workload (default); mpc: BASELINE config 3, batch of condensed "
                          "linear-MPC QPs (horizon 20, nx=12, nu=4 -> n=80, m=320) sharing H and A; c4: BASELINE config 4, "
                          "random dense QPs n=32, m=64")
+    ap.add_argument("--mpc-form", choices=["condensed", "sparse"], default="condensed",
+                    help="workload mpc: condensed (n=80, m=320; BASELINE config 3 as quoted) or the reference's own sparse form "
+                         "(loose_code/RandomLinMPC.py:54-66: n=320, m=560, 2.4 %% of A non-zero; streamed-operand MFMA kernel)")
     ap.add_argument("--full-ladder", action="store_true", help="setup(full_ladder=True): K(rho) for all 18 ladder entries of every "
                     "matrix as the reference builds them (default: a window of 5 with exact continuation)")
     ap.add_argument("--fresh-batches", type=int, default=4, help="distinct synthetic batches (one handle each) the timed steps "
@@ -93,10 +96,18 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ cpu_baseline leg
-def _mpc_controller():
+def _mpc_controller(form="condensed"):
     from reluqp import mpc
     Adyn, Bdyn = mpc.random_plant(12, 4, seed=0)                      # one plant, the batch is the initial states
-    return mpc.LinearMPC(Adyn, Bdyn, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="condensed")
+    return mpc.LinearMPC(Adyn, Bdyn, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form=form)
+
+
+def _nz_blocks(M, bs=16):
+    """Number of non-zero bs x bs blocks of a matrix (zero padded to multiples of bs)."""
+    r, c = M.shape
+    P = np.zeros(((r + bs - 1) // bs * bs, (c + bs - 1) // bs * bs))
+    P[:r, :c] = M != 0
+    return int((P.reshape(P.shape[0] // bs, bs, P.shape[1] // bs, bs).sum(axis=(1, 3)) != 0).sum())
 
 
 def cpu_worker(args):
@@ -109,7 +120,7 @@ def cpu_worker(args):
     dt = np.float32 if dtype == "f32" else np.float64
     ctl = x0 = None
     if args.workload == "mpc":
-        ctl = _mpc_controller()
+        ctl = _mpc_controller(args.mpc_form)
         x0 = np.random.RandomState(args.seed0 + 1).randn(args.batch, 12)
     t_setup = t_solve = 0.0
     iters = done = 0
@@ -138,7 +149,8 @@ def _run_cpu_mode(args, form, dtype, procs, threads, budget):
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         env[k] = str(threads)
     base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch), "--n", str(args.n),
-            "--n-eq", str(args.n_eq), "--n-ineq", str(args.n_ineq), "--eps-abs", str(args.eps_abs), "--seed0", str(args.seed0)]
+            "--n-eq", str(args.n_eq), "--n-ineq", str(args.n_ineq), "--eps-abs", str(args.eps_abs), "--seed0", str(args.seed0),
+            "--mpc-form", args.mpc_form]
     ps = [subprocess.Popen(base + ["--cpu-worker", "%s:%s:%d:%d:%g" % (form, dtype, r, procs, budget)], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(procs)]
     outs = []
@@ -192,11 +204,12 @@ def pmc_traffic(kernel, args, kern_s):
     (counters cannot be read from inside this process; the passes are separate `rocprofv3 --pmc FETCH_SIZE` /
     `--pmc WRITE_SIZE` runs of this same command, tools/pmc_collect.sh).  KB units, FETCH_SIZE doubled on gfx950
     (MI355X_MICROARCH.md).  None when no profile of this kernel on this workload is committed."""
-    sig = (args.workload, args.batch, args.n, args.n_eq, args.n_ineq, args.precision, args.tile)
+    sig = (args.workload if args.mpc_form == "condensed" else "mpc_sparse", args.batch, args.n, args.n_eq, args.n_ineq, args.precision, args.tile)
     table = {
         ("resident2", ("random_qp", 4096, 100, 25, 275, "f32", "same")): "r3_resident2/pmc.json",
         ("mfma", ("mpc", 4096, 100, 25, 275, "f32", "same")): "r3_mfma/pmc.json",
         ("mfma16", ("mpc", 4096, 100, 25, 275, "f32", "bf16")): "r3_mfma16/pmc.json",
+        ("mfmal", ("mpc_sparse", 4096, 100, 25, 275, "f32", "same")): "r3_mfmal/pmc.json",
         ("wave", ("c4", 8192, 32, 8, 56, "f32", "same")): "r3_wave/pmc.json",
     }
     name = table.get((kernel, sig))
@@ -245,9 +258,11 @@ def main():
     np_dt = np.float32 if args.precision == "f32" else np.float64
     batches = []
     t_gen = time.perf_counter()
+    blocks = None
     if args.workload == "mpc":
-        ctl = _mpc_controller()
+        ctl = _mpc_controller(args.mpc_form)
         n, m = ctl.H.shape[0], ctl.A.shape[0]
+        blocks = (_nz_blocks(ctl.A), _nz_blocks(ctl.H), ((n + 15) // 16) ** 2)      # (A, H, K) 16 x 16 blocks
         for i in range(nb):           # one plant; a batch is a set of initial states (H, A shared and un-batched)
             x0 = np.random.RandomState(args.seed0 + 1 + i).randn(start + B, 12)[start:]
             g, l, u = ctl.qp_vectors(x0)
@@ -351,9 +366,9 @@ def main():
         per = "/GPU" if args.scaling == "weak" else " total"
         fresh = ("%d distinct batches in rotation, every solve without dispatch history (= first solve of a fresh handle)" % nb)
         if args.workload == "mpc":
-            wl = ("batch=%d%s condensed linear-MPC QPs (horizon 20, nx=12, nu=4: n=%d, m=%d), H and A shared by the "
+            wl = ("batch=%d%s %s linear-MPC QPs (horizon 20, nx=12, nu=4: n=%d, m=%d), H and A shared by the "
                   "batch, random initial states seeds %d.., eps_abs=%g, cold start, reference defaults; %s"
-                  % (args.batch, per, n, m, args.seed0 + 1, args.eps_abs, fresh))
+                  % (args.batch, per, args.mpc_form, n, m, args.seed0 + 1, args.eps_abs, fresh))
             metric = "QP solves/sec (batch=%d linear-MPC QPs n=%d m=%d)" % (args.batch, n, m)
         else:
             wl = ("batch=%d%s random dense QPs n=%d m=%d (n_eq=%d), feasible rand_qp seeds %d.., eps_abs=%g, cold "
@@ -364,6 +379,16 @@ def main():
             roof = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                     "note": "dense algorithmic flops 2n^2+4mn per instance-iteration; the kernel skips all-zero operand groups of the "
                             "block-triangular MPC matrices, so it executes fewer"}
+        elif kernel == "mfmal":
+            # streamed-operand MFMA kernel: the work is the NON-ZERO 16 x 16 blocks of A (twice: A' nu and A dx) and H plus the
+            # dense K -- 512 flops per block and instance-iteration (every block is 4 v_mfma_f32_16x16x4_f32 over 16 instances)
+            bl = 2 * blocks[0] + blocks[1] + blocks[2]
+            tfb = rank_iters_max * bl * 512.0 / kern_avg_s / 1e12
+            roof = {"bound": "mfma", "achieved": tfb, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfb / FP32_MFMA_PEAK_TFLOPS,
+                    "note": "block-sparse algorithmic flops: 512 per non-zero 16x16 block of A (x2), H and the dense K = %d blocks per "
+                            "instance-iteration (the dense count 2n^2+4mn would be %.1fx that); operands stream from L2, "
+                            "1 KB per block and 16 instances" % (bl, f_iter / (bl * 512.0)),
+                    "blocks_per_iteration": bl, "l2_operand_gbs": rank_iters_max / 16.0 * bl * 1024.0 / kern_avg_s / 1e9}
         elif kernel == "mfma16":
             # three bf16 MFMAs per product term pair: the executed matrix flops are 3x the algorithmic ones; priced in ALGORITHMIC
             # flops against the dense bf16 matrix peak (the kernel is bound by its VALU / LDS phases, not by this roof)

@@ -28,6 +28,7 @@
 #include "rqp_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -36,18 +37,25 @@ constexpr int ML_NP = 16 * ML_NB, ML_MP = 16 * ML_MB;
 constexpr int ML_KB1 = ML_MB + ML_NB, ML_KB2 = ML_NB;              // k blocks of GEMM1 (60: A's rows, then H's) / GEMM2, GEMM3 (20)
 constexpr int ML_TN = (ML_NB + ML_NW - 1) / ML_NW;                // n tiles per wave (3)
 constexpr int ML_TM = ML_MB / ML_NW;                               // m tiles per wave (5)
-constexpr int ML_D = 8;                                            // groups in flight per wave
-constexpr int ML_CAP1 = ML_TN * ML_KB1, ML_CAP3 = ML_TM * ML_KB2, ML_CAP2 = ML_TN * ML_KB2;   // stream capacities per wave (groups)
+constexpr int ML_D = 5;                                            // groups in flight per wave
+constexpr int ml_up(int v) { return (v + ML_D - 1) / ML_D * ML_D; }
+constexpr int ML_CAP1 = ml_up(ML_TN * ML_KB1), ML_CAP3 = ml_up(ML_TM * ML_KB2), ML_CAP2 = ml_up(ML_TN * ML_KB2);   // stream capacities per wave (groups)
+constexpr int ML_LAST = 1 << 16, ML_NULL = 1 << 17;               // stream entry flags
 static_assert(ML_MB % ML_NW == 0, "tiling");
 
-// image layout (4-byte words).  A stream entry: blk | tile << 8 | (last group of the tile) << 16.
-//   meta  int [32]              : ng1[8], ng3[8], ng2[8] (groups of wave w's streams), -
-//   kx1   int [8][CAP1]   kx3 int [8][CAP3]   kx2 int [8][CAP2]
+// image layout (4-byte words).  A stream entry: blk | tile << 8 | ML_LAST (last group of the tile); streams are padded to
+// multiples of ML_D groups with ML_NULL entries (no MFMAs; they keep the ring's slot order across streams).
+//   meta  int [32]              : ng1[8], ng3[8], ng2[8] (padded group counts of wave w's streams), [24] blocks per tile of stream 2
+//   kb    int [8][TB]           : what the solve kernel reads (copied to LDS): one byte per group, blk | 0x40 last | 0x80 null;
+//                                 stream 2 is dense and regular (tiles x nb5 blocks 0 .. nb5-1): it needs no table
+//   kx1   int [8][CAP1]   kx3 int [8][CAP3]   kx2 int [8][CAP2]   (setup only: the entries with their tiles, for k_pack_mfmal)
 //   nzf   int [NB * KB1 + MB * KB2]   non-zero flags of the 16 x 16 blocks (setup scratch)
 //   W1    f32 [8][CAP1][64][4]  S'[16 t + i16][16 blk + 4 kq + j],  S = [A (MP rows); H' (NP rows)]
 //   W3    f32 [8][CAP3][64][4]  A[16 T + i16][16 blk + 4 kq + j]
 //   K     f32 [nrho][8][CAP2][64][4]   K_j[16 t + i16][16 blk + 4 kq + j]
-constexpr size_t ML_OFF_KX1 = 32, ML_OFF_KX3 = ML_OFF_KX1 + 8 * ML_CAP1, ML_OFF_KX2 = ML_OFF_KX3 + 8 * ML_CAP3;
+constexpr int ML_TB1 = 2 * (ML_CAP1 / ML_D) + 4, ML_TB3 = 2 * (ML_CAP3 / ML_D) + 4, ML_TB = ML_TB1 + ML_TB3;   // byte tables (dwords)
+constexpr size_t ML_OFF_KB = 32;                                   // kb [8][TB]: stream 1 | stream 3 of wave w: 8 BYTES per block of 5 groups
+constexpr size_t ML_OFF_KX1 = ML_OFF_KB + 8 * ML_TB, ML_OFF_KX3 = ML_OFF_KX1 + 8 * ML_CAP1, ML_OFF_KX2 = ML_OFF_KX3 + 8 * ML_CAP3;
 constexpr size_t ML_OFF_NZ = ML_OFF_KX2 + 8 * ML_CAP2;
 constexpr size_t ML_NNZ = (size_t)ML_NB * ML_KB1 + (size_t)ML_MB * ML_KB2;
 constexpr size_t ML_OFF_W1 = ML_OFF_NZ + ML_NNZ;
@@ -57,7 +65,7 @@ static_assert(ML_OFF_W1 % 4 == 0 && ML_OFF_W3 % 4 == 0 && ML_OFF_K % 4 == 0, "fl
 
 constexpr size_t ml_lds_floats() {
     return (size_t)(ML_KB1 + 2 * ML_NB + ML_MB) * 256     // V1 | V3 | DV | AD (red, rr of a check alias AD)
-           + 64 + 8 * 16;                                  // rho ladder | inst
+           + 64 + 8 * 16 + 8 * ML_TB;                      // rho ladder | inst | stream tables
 }
 
 __device__ __forceinline__ float nanmaxl(float a, float b) {          // NaN-propagating max (torch semantics)
@@ -71,7 +79,9 @@ __device__ __forceinline__ void lds_barrier() {          // orders LDS only: the
 
 }   // namespace
 
-__global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float* __restrict__ img) {
+// DIAG = true is a separate diagnostic build (RQP_DIAG=1): s_memtime stamps accumulate the ticks each wave spends per segment.
+template <bool DIAG, int EXP = 0>     // EXP != 0: timing experiments of the diagnostic build (wrong results): 1 no operand loads, 2 no MFMAs, 3 no vector reads
+__global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float* __restrict__ img, unsigned long long* __restrict__ dbg) {
     constexpr int NW = ML_NW, NT = ML_NT, NB = ML_NB, MB = ML_MB, TN = ML_TN, TM = ML_TM, D = ML_D;
     extern __shared__ __attribute__((aligned(16))) float sml[];
     f32x4* V1 = (f32x4*)sml;                 // [KB1][64]: blocks < MB: nu (lam / 0 at a check); blocks MB..: x (0 at a check)
@@ -83,6 +93,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     float* rhosf = (float*)(AD + MB * 64);   // [64]
     float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 4 rho index, 5 done
     int* inst_i = (int*)inst;
+    int* tabs = (int*)(inst + 8 * 16);       // [NW][TB] this wave's stream tables (bytes)
 
     const int n = a.n, m = a.m;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -93,13 +104,16 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     const int kmax = a.max_iter;
     const int* meta = (const int*)img;
     const int ng1 = __builtin_amdgcn_readfirstlane(meta[wave_u]), ng3 = __builtin_amdgcn_readfirstlane(meta[8 + wave_u]);
-    const int ng2 = __builtin_amdgcn_readfirstlane(meta[16 + wave_u]);
-    const int* kx1 = meta + ML_OFF_KX1 + wave_u * ML_CAP1;
-    const int* kx3 = meta + ML_OFF_KX3 + wave_u * ML_CAP3;
-    const int* kx2 = meta + ML_OFF_KX2 + wave_u * ML_CAP2;
-    const f32x4* W1 = (const f32x4*)(img + ML_OFF_W1) + (size_t)wave_u * ML_CAP1 * 64;     // (uniform bases: the loads are saddr + 16 lane)
-    const f32x4* W3 = (const f32x4*)(img + ML_OFF_W3) + (size_t)wave_u * ML_CAP3 * 64;
-    const f32x4* Kw = (const f32x4*)(img + ML_OFF_K) + (size_t)wave_u * ML_CAP2 * 64;            // + j * (KJ / 4)
+    const int ng2 = __builtin_amdgcn_readfirstlane(meta[16 + wave_u]);   // (tiles of the dense stream x nb5)
+    // streams: buffer loads -- scalar byte offset from the image + 16 lane (no vector ALU in the address)
+    const __amdgpu_buffer_rsrc_t imgr = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, 0x7fffffff, 0x00020000);
+    const unsigned oW1 = (unsigned)(ML_OFF_W1 + (size_t)wave_u * ML_CAP1 * 256) * 4u;
+    const unsigned oW3 = (unsigned)(ML_OFF_W3 + (size_t)wave_u * ML_CAP3 * 256) * 4u;
+    const unsigned oK0 = (unsigned)(ML_OFF_K + (size_t)wave_u * ML_CAP2 * 256) * 4u;              // + j * KJ * 4
+    const int* tab1 = tabs + wave_u * ML_TB;
+    const int* tab3 = tab1 + ML_TB1;
+    const int nb5 = __builtin_amdgcn_readfirstlane(meta[24]);       // blocks per tile of the dense stream (a multiple of D)
+    for (int i = lane; i < ML_TB; i += 64) tabs[wave_u * ML_TB + i] = meta[ML_OFF_KB + wave_u * ML_TB + i];
     // (lv: the lane number through an opaque copy per loop iteration -- hipcc otherwise hoists every (array, tile) address of
     //  the unrolled state code out of the solve loop and spills them)
     int lv = lane;
@@ -152,45 +166,119 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
         }
     }
 
-    // ---- the operand ring: D groups in flight (operands + stream entries), shared by the three GEMMs
+    // ---- the operand ring: D groups in flight, shared by the three GEMMs.  Every visit of a slot consumes it and requests one
+    //      new group into the slot of the visit BEFORE it (whose registers are free), unconditionally: the slot order is
+    //      periodic across the streams (whose lengths are multiples of D) and a request is always D - 1 visits ahead of its use.
+    //      NO VECTOR-ALU INSTRUCTION inside the visit loops: the float32 MFMA shares its lanes with the VALU, and one v_add per
+    //      visit (an address) cost 38 cycles of a 128-cycle visit (RQP_DIAG experiments) -- operand addresses are scalar bases
+    //      + immediates, the dense stream's vector operands sit at compile-time LDS offsets.
     f32x4 o_[D];
-    int kv[D];
-    auto pro = [&](const f32x4* ops, const int* kx, int ng) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const int gi = j < ng ? j : ng - 1;
-            o_[j] = *(const f32x4*)((const char*)(ops + (size_t)gi * 64) + (unsigned)lv * 16u);
-            kv[j] = kx[gi];
-        }
+    auto fetch = [&](int j, unsigned base) __attribute__((always_inline)) {             // base: uniform byte offset of slot 0's group
+        if constexpr (EXP != 1)
+            o_[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(imgr, (unsigned)lv * 16u, base + 1024u * (unsigned)j, 0));
     };
-    // acc over the stream; at a tile's last group the sum goes to Out[tile] (this lane's own float4 of the D layout)
-    auto body = [&](const f32x4* ops, const int* kx, int ng, const f32x4* Bv, f32x4* Out) __attribute__((always_inline)) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int g0 = 0; g0 < ng; g0 += D) {
+    auto pro = [&](unsigned off) __attribute__((always_inline)) {      // (slot D - 1 is requested by the first visit)
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) fetch(j, off);
+    };
+    // SPARSE stream X (ng groups, a multiple of D, entries tab[]: 8 bytes per block of D); at a tile's last group the sum goes to
+    // Out[tile] (this lane's own float4 of the D layout; the tiles of a stream are wave, wave + NW, ...).  The slots are refilled
+    // from X, in the last block from the head of the NEXT stream (offY).  (One v_add per visit remains: the LDS address.)
+    auto body = [&](unsigned offX, int ng, unsigned offY, const int* tab, const f32x4* Bv, f32x4* Out) __attribute__((always_inline)) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;          // two chains: a dependent MFMA waits 40 cycles, an independent one 32
+        int kA = __builtin_amdgcn_readfirstlane(tab[0]), kB = __builtin_amdgcn_readfirstlane(tab[1]), kN = __builtin_amdgcn_readfirstlane(tab[2]);
+        int tile = wave_u;
+        f32x4 bn = Bv[(kA & 63) * 64 + lv];                          // the vector operand is read one visit ahead
+        auto block = [&](int g0, bool own) __attribute__((always_inline)) {
+            const int q = (g0 / D) * 2;
+            const int nB = tab[q + 3], nN = tab[q + 4];              // the next block's entries (VGPR copies until the block's end)
+            const unsigned pr = own ? offX + 1024u * (unsigned)(g0 + D) : offY;
+            const unsigned p0 = offX + 1024u * (unsigned)g0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const int g = g0 + j;
-                if (g >= ng) break;
-                const int kd = kv[j];
-                const f32x4 b = Bv[(kd & 0xff) * 64 + lv];
+                const int e = (j < 4 ? (kA >> (8 * j)) : kB) & 0xff;
+                const int en = j < 3 ? (kA >> (8 * (j + 1))) : (j == 3 ? kB : kN);
+                const f32x4 b = bn;
                 const f32x4 av = o_[j];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc, 0, 0, 0);
-                const int gn = g + D;
-                if (gn < ng) {
-                    o_[j] = *(const f32x4*)((const char*)(ops + (size_t)gn * 64) + (unsigned)lv * 16u);
-                    kv[j] = kx[gn];
+                if (j == 0) fetch(D - 1, p0); else fetch(j - 1, pr);  // (fetch adds 1024 x slot)
+                if constexpr (EXP != 3) bn = Bv[(en & 63) * 64 + lv];   // (past the stream's end: a valid LDS address, value unused)
+                __builtin_amdgcn_sched_barrier(0);                   // (the requests stay ahead of this visit's MFMAs)
+                if (EXP != 2 && !(e & 0x80)) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc2, 0, 0, 0);
                 }
-                if (__builtin_amdgcn_readfirstlane(kd) >> 16) {      // (uniform) last group of a tile
-                    Out[((kd >> 8) & 0xff) * 64 + lv] = acc;
+                if (e & 0x40) {                                      // (uniform) last group of a tile
+                    Out[tile * 64 + lv] = acc + acc2;
                     acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc2 = acc;
+                    tile += NW;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            kA = kN;
+            kB = __builtin_amdgcn_readfirstlane(nB);
+            kN = __builtin_amdgcn_readfirstlane(nN);
+        };
+        int g0 = 0;
+        for (; g0 + D < ng; g0 += D) block(g0, true);
+        block(g0, false);
+    };
+    // DENSE stream (K_j): ntw tiles of nb5 blocks 0 .. nb5 - 1 each (nb5 = 5, 10, 15 or 20; blocks past ceil(n / 16) have zero
+    // operands).  Block p of a tile multiplies DV[p]: every LDS offset is an immediate.  The first operand of a chunk of 5 is read
+    // at the end of the chunk before it -- both candidates (the next chunk's, and block 0 for a new tile).
+    auto body_dense = [&](unsigned offX, int ntw, unsigned offY, f32x4* Out) __attribute__((always_inline)) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+        int tile = wave_u;
+        int left = ntw * (nb5 / D);                                  // chunks to go
+        unsigned px = offX;
+        // vector operands: bq[j] serves visit j of a chunk; read TWO visits ahead (LDS returns queue behind the operand
+        // stream's returns).  The reads for the first two visits of the next chunk are issued for both candidates: the next
+        // chunk of the same tile (blocks pb + 2) and the first chunk of the next tile (blocks 0, 1).
+        f32x4 bq[D], bw0 = DV[lv], bw1 = DV[64 + lv], bc0 = bw0, bc1 = bw1;
+        for (int tl = 0; tl < ntw; ++tl) {
+#pragma unroll
+            for (int c = 0; c < NB / D; ++c) {
+                if (c * D < nb5) {                                   // (uniform)
+                    left -= 1;
+                    const unsigned pr = left ? px + 1024u * D : offY;
+                    bq[0] = c == 0 ? bw0 : bc0;
+                    bq[1] = c == 0 ? bw1 : bc1;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {                    // visit: MFMA, vector read, MFMA, request, MFMA, MFMA
+                        const int pb = c * D + j;
+                        const f32x4 b = bq[j];
+                        const f32x4 av = o_[j];
+                        if constexpr (EXP != 2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (EXP != 3) {
+                            if (j + 2 < D) bq[j + 2] = DV[(pb + 2) * 64 + lv];
+                            else if (j + 2 == D) { bc0 = DV[(pb + 2) * 64 + lv]; bw0 = DV[lv]; }             // (blocks NB, NB + 1: behind DV, unused)
+                            else { bc1 = DV[(pb + 2) * 64 + lv]; bw1 = DV[64 + lv]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (EXP != 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc2, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j == 0) fetch(D - 1, px); else fetch(j - 1, pr);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (EXP != 2) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc2, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    px += 1024u * D;
                 }
             }
+            Out[tile * 64 + lv] = acc + acc2;
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc2 = acc;
+            tile += NW;
         }
     };
-    pro(W3, kx3, ng3);
+    const int ntw2 = ng2 / nb5;
+    pro(oW3);
     __syncthreads();
     int ri_l = inst_i[4 * 16 + i16];
     float rho_ne = 1.f, rho_eq = 1.f, inv_ne = 1.f, inv_eq = 1.f;
@@ -224,17 +312,32 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     bool final_chk = false;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 
+    unsigned long long t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int seg) __attribute__((always_inline)) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0 && ph == 1) t_acc[seg] += t - t_last;
+            t_last = t;
+        }
+    };
+    stamp(-1);
     while (true) {
         asm volatile("" : "+v"(lv));
         lds_barrier();
+        stamp(0);
         unsigned long long todo = 0;
         int jr = 0;
         if (ph != 0) {                                   // ---------------- GEMM1: S' V1 for this wave's n tiles
-            body(W1, kx1, ng1, V1, ph == 3 ? V3 : DV);
-            if (ph == 1) {                                           // (the next GEMM's first groups are requested before the epilogue)
+            if (ph == 1) {                                           // (GEMM2's first groups are requested during GEMM1)
                 todo = __ballot(lane < 16);
                 jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
-                pro(Kw + (size_t)jr * (ML_KJ / 4), kx2, ng2);
+            }
+            body(oW1, ng1, ph == 1 ? oK0 + (unsigned)jr * (unsigned)(ML_KJ * 4) : oW1, tab1, V1, ph == 3 ? V3 : DV);
+            stamp(1);
+            if (ph == 1) {
 #pragma unroll
                 for (int e = 0; e < TN; ++e)                         // d = H x + g + A' nu
                     if (wave_u + NW * e < NB) {
@@ -242,10 +345,10 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                         d[0] += gs[e][0]; d[1] += gs[e][1]; d[2] += gs[e][2]; d[3] += gs[e][3];
                         DV[(wave_u + NW * e) * 64 + lv] = d;
                     }
-            } else {
-                pro(W1, kx1, ng1);
             }
+            stamp(2);
             lds_barrier();                                           // V1 is free again (ph 2 rewrites it); d is visible (ph 1)
+            stamp(3);
         }
         bool run_g3 = (ph == 0);
         if (ph == 1) {                                   // ---------------- GEMM2: dx = -K_j d for this wave's n tiles, K_j per column
@@ -253,14 +356,11 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
             bool first_pass = true;
             while (true) {                                           // one pass per distinct rho index of the tile (usually one)
                 const bool mine = (ri_l == jr);
-                body(Kw + (size_t)jr * (ML_KJ / 4), kx2, ng2, DV, V3);
+                const int jc = jr;
                 todo &= ~__ballot(lane < 16 && ri_l == jr);
-                if (todo) {
-                    jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
-                    pro(Kw + (size_t)jr * (ML_KJ / 4), kx2, ng2);
-                } else {
-                    pro(W3, kx3, ng3);
-                }
+                if (todo) jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
+                body_dense(oK0 + (unsigned)jc * (unsigned)(ML_KJ * 4), ntw2, todo ? oK0 + (unsigned)jr * (unsigned)(ML_KJ * 4) : oW3, V3);
+                stamp(4);
 #pragma unroll
                 for (int e = 0; e < TN; ++e)
                     if (wave_u + NW * e < NB) {
@@ -286,7 +386,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                     V1[(MB + t) * 64 + lv] = xv;
                 }
             }
+            stamp(5);
             lds_barrier();
+            stamp(6);
             run_g3 = true;
         }
         bool nu_done = false;
@@ -294,8 +396,8 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
             const bool upd = (ph == 1);
             const bool fin_next = upd && (k + 1 >= kmax) && (to_chk != 1);
             const bool with_nu = upd && to_chk != 1 && !fin_next;
-            body(W3, kx3, ng3, V3, AD);
-            pro(W1, kx1, ng1);
+            body(oW3, ng3, oW1, tab3, V3, AD);
+            stamp(7);
 #pragma unroll
             for (int tl = 0; tl < TM; ++tl) {
                 const int T = wave_u + NW * tl;
@@ -333,7 +435,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                     V1[T * 64 + lv] = nu;
                 }
             }
+            stamp(8);
             if (upd) {
+                if constexpr (DIAG) t_acc[11] += 1;
                 k += 1;
                 to_chk -= 1;
             }
@@ -524,6 +628,11 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
             make_nu();                                   // (V1's x rows hold x again since ph 2)
             ph = 1;
         }
+        if (ph == 1) stamp(9); else stamp(-1);
+    }
+    if constexpr (DIAG) {
+        if (lane == 0)
+            for (int e = 0; e < 12; ++e) dbg[((size_t)blockIdx.x * NW + wave) * 12 + e] = t_acc[e];
     }
 }
 
@@ -569,8 +678,9 @@ __global__ void k_meta_mfmal(int n, int m, float* __restrict__ img) {
         for (int blk = 0; blk < ML_KB1; ++blk)
             if (nzf[t * ML_KB1 + blk]) kx[pos++] = blk | (t << 8);
         if (pos == first) kx[pos++] = 0 | (t << 8);
-        kx[pos - 1] |= 1 << 16;
+        kx[pos - 1] |= ML_LAST;
     }
+    while (pos % ML_D) kx[pos++] = ML_NULL;
     meta[w] = pos;
     kx = meta + ML_OFF_KX3 + w * ML_CAP3;
     pos = 0;
@@ -580,21 +690,37 @@ __global__ void k_meta_mfmal(int n, int m, float* __restrict__ img) {
         for (int blk = 0; blk < ML_KB2; ++blk)
             if (nzf[ML_NB * ML_KB1 + T * ML_KB2 + blk]) kx[pos++] = blk | (T << 8);
         if (pos == first) kx[pos++] = 0 | (T << 8);
-        kx[pos - 1] |= 1 << 16;
+        kx[pos - 1] |= ML_LAST;
     }
+    while (pos % ML_D) kx[pos++] = ML_NULL;
     meta[8 + w] = pos;
     kx = meta + ML_OFF_KX2 + w * ML_CAP2;
     pos = 0;
-    for (int e = 0; e < ML_TN; ++e) {                                 // K_j is dense: the blocks of the problem's own n
+    const int nb5 = (nbt + ML_D - 1) / ML_D * ML_D;
+    for (int e = 0; e < ML_TN; ++e) {                                 // K_j is dense: nb5 blocks for each tile of the problem's own n
         const int t = w + ML_NW * e;
-        if (t >= ML_NB) break;
-        if (t < nbt)
-            for (int blk = 0; blk < nbt; ++blk) kx[pos++] = blk | (t << 8);
-        else
-            kx[pos++] = 0 | (t << 8);
-        kx[pos - 1] |= 1 << 16;
+        if (t >= nbt) break;
+        for (int blk = 0; blk < nb5; ++blk) kx[pos++] = blk | (t << 8) | (blk >= nbt ? ML_NULL : 0);
     }
     meta[16 + w] = pos;
+    if (w == 0) meta[24] = nb5;
+    // the byte tables the solve kernel reads (streams 1 and 3): 8 bytes per block of ML_D groups
+    unsigned char* kb = (unsigned char*)(meta + ML_OFF_KB + w * ML_TB);
+    for (int st = 0; st < 2; ++st) {
+        const int* src = meta + (st == 0 ? ML_OFF_KX1 + w * ML_CAP1 : ML_OFF_KX3 + w * ML_CAP3);
+        const int cnt = meta[(st == 0 ? 0 : 8) + w];
+        const int tbd = st == 0 ? ML_TB1 : ML_TB3;
+        for (int i = 0; i < 4 * tbd; ++i) {
+            const int blkno = i >> 3, j = i & 7, g = blkno * ML_D + j;
+            unsigned char v = 0x80;
+            if (j < ML_D && g < cnt) {
+                const int kd = src[g];
+                v = (unsigned char)((kd & 63) | ((kd & ML_LAST) ? 0x40 : 0) | ((kd & ML_NULL) ? 0x80 : 0));
+            }
+            kb[i] = v;
+        }
+        kb += 4 * tbd;
+    }
 }
 
 // operand images of the streams (after k_meta_mfmal); groups past a stream's end are zero
@@ -612,7 +738,7 @@ __global__ void k_pack_mfmal(int n, int m, int ldn, int nrho, const float* __res
             float v = 0.f;
             if (pos < meta[w]) {
                 const int kd = meta[ML_OFF_KX1 + grp], blk = kd & 0xff, t = (kd >> 8) & 0xff;
-                v = ml_s_elem(n, m, ldn, A, Ht, 16 * blk + 4 * kq + j, 16 * t + i16);
+                if (!(kd & ML_NULL)) v = ml_s_elem(n, m, ldn, A, Ht, 16 * blk + 4 * kq + j, 16 * t + i16);
             }
             W1[idx] = v;
         } else if (idx < ML_N1 + ML_N3) {
@@ -622,7 +748,7 @@ __global__ void k_pack_mfmal(int n, int m, int ldn, int nrho, const float* __res
             if (pos < meta[8 + w]) {
                 const int kd = meta[ML_OFF_KX3 + grp], blk = kd & 0xff, T = (kd >> 8) & 0xff;
                 const int r = 16 * T + i16, c = 16 * blk + 4 * kq + j;
-                if (r < m && c < n) v = A[(size_t)r * ldn + c];
+                if (r < m && c < n && !(kd & ML_NULL)) v = A[(size_t)r * ldn + c];
             }
             W3[o] = v;
         } else {
@@ -632,7 +758,7 @@ __global__ void k_pack_mfmal(int n, int m, int ldn, int nrho, const float* __res
             if (pos < meta[16 + w]) {
                 const int kd = meta[ML_OFF_KX2 + grp], blk = kd & 0xff, t = (kd >> 8) & 0xff;
                 const int r = 16 * t + i16, c = 16 * blk + 4 * kq + j;
-                if (r < n && c < n) v = K[((size_t)jr * n + r) * ldn + c];
+                if (r < n && c < n && !(kd & ML_NULL)) v = K[((size_t)jr * n + r) * ldn + c];
             }
             Kimg[o] = v;
         }
@@ -654,10 +780,48 @@ hipError_t rqp_launch_pack_mfmal(const rqp_handle* h, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t rqp_prepare_mfmal(const rqp_handle* h) {
-    (void)h;
-    return rqp_raise_lds_limit((const void*)k_admm_mfmal, ml_lds_floats() * sizeof(float));
+    hipError_t e = rqp_raise_lds_limit((const void*)k_admm_mfmal<false>, ml_lds_floats() * sizeof(float));
+    if (e == hipSuccess && (h->debug & 2)) {
+        (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 1>, ml_lds_floats() * sizeof(float));
+        (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 2>, ml_lds_floats() * sizeof(float));
+        (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 3>, ml_lds_floats() * sizeof(float));
+        (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 4>, ml_lds_floats() * sizeof(float));
+        e = rqp_raise_lds_limit((const void*)k_admm_mfmal<true>, ml_lds_floats() * sizeof(float));
+    }
+    return e;
 }
 hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
-    k_admm_mfmal<<<(h->B + 15) / 16, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img);
+    const int grid = (h->B + 15) / 16;
+    if (h->debug & 2) {          // diagnostic build: per-segment tick shares of the iteration (synchronous, debug only)
+        unsigned long long* dbg = nullptr;
+        const size_t cnt = (size_t)grid * ML_NW * 12;
+        if (hipMalloc((void**)&dbg, cnt * 8) != hipSuccess) return hipErrorOutOfMemory;
+        const char* ex = getenv("RQP_MLEXP");
+        const int exv = ex ? atoi(ex) : 0;
+        if (exv == 1) k_admm_mfmal<true, 1><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
+        else if (exv == 2) k_admm_mfmal<true, 2><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
+        else if (exv == 3) k_admm_mfmal<true, 3><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
+        else if (exv == 4) k_admm_mfmal<true, 4><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
+        else k_admm_mfmal<true><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> hb(cnt);
+        (void)hipMemcpy(hb.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        static const char* names[10] = {"top wait", "GEMM1", "d", "wait", "GEMM2", "x", "wait", "GEMM3", "rows", "next"};
+        for (int w = 0; w < ML_NW; ++w) {
+            double tot[12] = {0};
+            for (int t = 0; t < grid; ++t)
+                for (int e2 = 0; e2 < 12; ++e2) tot[e2] += (double)hb[((size_t)t * ML_NW + w) * 12 + e2];
+            fprintf(stderr, "[rqp diag mfmal] wave %d, %.1f iterations/workgroup, s_memtime ticks per iteration:", w, tot[11] / grid);
+            double it = 0;
+            for (int e2 = 0; e2 < 10; ++e2) {
+                fprintf(stderr, "  %s %.1f", names[e2], tot[e2] / tot[11]);
+                it += tot[e2];
+            }
+            fprintf(stderr, "  | sum %.1f\n", it / tot[11]);
+        }
+        return hipGetLastError();
+    }
+    k_admm_mfmal<false><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, nullptr);
     return hipGetLastError();
 }
