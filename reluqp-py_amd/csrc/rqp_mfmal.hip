@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                 todo = __ballot(lane < 16);
                 jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
             }
-            body(oW1, ng1, ph == 1 ? oK0 + (unsigned)jr * (unsigned)(ML_KJ * 4) : oW1, tab1, V1, ph == 3 ? V3 : DV);
+            // (the ring's next stream: K_j in an iteration -- unless this wave owns no tile of the dense stream -- else GEMM1 again)
+            body(oW1, ng1, ph == 1 ? (ntw2 ? oK0 + (unsigned)jr * (unsigned)(ML_KJ * 4) : oW3) : oW1, tab1, V1, ph == 3 ? V3 : DV);
             stamp(1);
             if (ph == 1) {
 #pragma unroll
