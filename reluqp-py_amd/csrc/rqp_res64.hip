@@ -83,6 +83,31 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int rr = lane >> 2, cc = lane & 3;
+    // rho-ladder window (rqp_common.h; same protocol as k_admm_res2): K slot s of this instance holds ladder index wb + s.
+    // SolveArgs.cont = 2: only the instances that left their window (cstat = 1), resumed EXACTLY behind the check they left at.
+    int ri = a.rho_ind[b];
+    int k0 = 0;
+    bool exact = false;
+    if (a.cont == 2) {
+        if (a.cstat[b] == 0) return;
+        const int ci = a.cont_iter[b];
+        if (ci >= 0) {
+            k0 = ci;
+            exact = true;
+        }
+    }
+    const int wb = a.wbase ? a.wbase[(a.sK == 0) ? 0 : b] : 0;
+    if (a.cstat && a.mode == 0) {
+        const int sl = ri - wb;
+        if (sl < 0 || sl >= a.kwin) {                                 // (uniform) the incoming index lies outside the window: leave
+            if (tid == 0) {                                           // untouched; rqp_solve re-centres the window and restarts it
+                a.cstat[b] = 1;
+                if (!exact) a.cont_iter[b] = -1;
+                atomicAdd(a.ncont, 1);
+            }
+            return;
+        }
+    }
     // Waves w and w + 4 share a SIMD; VALU issue is arbitrated by priority, then age, so the second-dispatched half loses every
     // segment (RQP_DIAG: A' nu + H x 2 624 vs 2 263 cycles) and the first half waits for it at each barrier.  One static
     // priority step for that half evens the pair out (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
@@ -104,15 +129,16 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         const int col = i / N, row = i % N;
         Hs[i] = (row < n && col < n) ? Ht[(size_t)col * ldn + row] : 0.0;      // Ht = sym(H): H[row][col] = Ht[col][row]
     }
-    int ri = a.rho_ind[b];
     if (tid < 32) rhoL[tid] = (tid < a.nrho) ? a.rhos[tid] : 0.0;   // (nrho <= 32: rqp_res64_fits)
     double kr[KC];
     auto load_K = [&](int j) {
         const int krow = CW * wave + rr;
+        int sl = j - wb;                                              // (iterate / compute_residuals: rqp_abi re-centres the windows first)
+        sl = sl < 0 ? 0 : (sl >= a.kwin ? a.kwin - 1 : sl);
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int col = KC * cc + c;
-            kr[c] = (rr < CW && krow < n && col < n) ? Kb[((size_t)j * n + krow) * ldn + col] : 0.0;
+            kr[c] = (rr < CW && krow < n && col < n) ? Kb[((size_t)sl * n + krow) * ldn + col] : 0.0;
         }
     };
     load_K(ri);
@@ -272,16 +298,21 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     if (tid == 0) {
         stat[0] = 0.0;                                                // pri
         stat[1] = 0.0;                                                // dua
-        stat[2] = (a.mode == 2) ? a.rho_in : a.rhos[ri];              // carried rho estimate, reluqpth.py:211
+        stat[2] = (a.mode == 2) ? a.rho_in : (exact ? a.cont_rho[b] : a.rhos[ri]);   // carried rho estimate, reluqpth.py:211
     }
     bool converged = false;
     int iters = 0;
     const int kmax = (a.mode == 2) ? 0 : a.max_iter;
 
-    // A x of the incoming state
-    prod_A(x);
-    __syncthreads();
-    row_pass(true, false, kmax > 0);
+    // A x of the incoming state (an exact continuation brought it along: only lam_hat / nu of the next iteration are due)
+    if (!exact) {
+        prod_A(x);
+        __syncthreads();
+        row_pass(true, false, kmax > 0);
+    } else {
+        zt = rin ? a.ax[(size_t)b * m + tid] : 0.0;
+        row_pass(false, false, k0 < kmax);
+    }
 
     // compute_residuals (reluqpth.py:307-318) on the current state; leaves (H x)[col] of the column owners in hxv
     // updates stat[0..4] = pri, dua, rho estimate (carried, Q4), scale of pri, scale of dua; ends with a barrier
@@ -369,7 +400,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
     };
     stamp(-1);
     int to_chk = a.check_interval;
-    for (int k = 1; k <= kmax; ++k) {
+    for (int k = k0 + 1; k <= kmax; ++k) {                            // (k0 > 0: an exact continuation, on the check grid)
         __syncthreads();                                              // B3: nu (and x) visible
         stamp(0);
         const double d = prod_At(true, true, nuL);                    // d = H x + g + A' nu   (own columns)
@@ -416,6 +447,24 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
                 break;
             }
             if (ri != ri_before) {                                    // adaptive-rho "re-factor": table lookup
+                if (a.cstat && k < kmax && (ri < wb || ri >= wb + a.kwin)) {
+                    // the new index has no K in this instance's window: leave with the exact state; rqp_solve re-factors a
+                    // window around ri and continues the instance behind this check (SolveArgs.cont = 2)
+                    if (xin) a.x[(size_t)b * n + xcol] = x;
+                    if (rin) {
+                        a.z[(size_t)b * m + tid] = z;
+                        a.lam[(size_t)b * m + tid] = lam;
+                        a.ax[(size_t)b * m + tid] = zt;
+                    }
+                    if (tid == 0) {
+                        a.rho_ind[b] = ri;
+                        a.cont_iter[b] = k;
+                        a.cont_rho[b] = stat[2];
+                        a.cstat[b] = 1;
+                        atomicAdd(a.ncont, 1);
+                    }
+                    return;
+                }
                 load_K(ri);
                 set_rho(ri);
             }
@@ -478,7 +527,10 @@ __global__ void __launch_bounds__(512, 2) k_admm_res64(SolveArgs a, unsigned lon
         a.z[(size_t)b * m + tid] = keep ? z : 0.0;
         a.lam[(size_t)b * m + tid] = keep ? lam : 0.0;
     }
-    if (tid == 0) a.rho_ind[b] = keep ? ri : a.rho_ind0;
+    if (tid == 0) {
+        a.rho_ind[b] = keep ? ri : a.rho_ind0;
+        if (a.cstat) a.cstat[b] = 0;
+    }
 }
 
 bool rqp_res64_fits(const rqp_handle* h) { return h->esz == 8 && h->n <= R64_N && h->m <= R64_M && h->nrho <= 32; }

@@ -57,6 +57,9 @@ CASES = [  # (precision, kernel, n, n_eq, n_ineq, feasible, settings)
     (torch.float32, "resident", 40, 10, 70, False, dict(max_iter=400)),
     (torch.float64, "generic", 30, 8, 50, True, dict(eps_abs=1e-7, max_iter=2000)),
     (torch.float32, "resident", 100, 25, 275, True, dict(eps_abs=1e-4)),
+    (torch.float64, "resident", 10, 5, 15, False, dict(max_iter=600)),               # k_admm_res64
+    (torch.float64, "resident", 40, 10, 70, False, dict(max_iter=400, check_interval=10)),
+    (torch.float64, "resident", 100, 25, 275, True, dict(eps_abs=1e-6)),
 ]
 
 
@@ -123,15 +126,15 @@ def test_window_follows_golden_e6_trajectory(golden):
     _same(snaps[False], snaps[True], "eps_abs = 1e-6 batch")
 
 
-@pytest.mark.parametrize("prec,xtol", [(torch.float64, 1e-8), (torch.float32, 2e-5)])
-def test_window_g1_chain_below_the_window(golden, prec, xtol):
+@pytest.mark.parametrize("prec,xtol,k64", [(torch.float64, 1e-8, "generic"), (torch.float32, 2e-5, None), (torch.float64, 1e-8, "resident")])
+def test_window_g1_chain_below_the_window(golden, prec, xtol, k64):
     """The reference's built-in QP (reluqpth.py:342-346) as a windowed batch of 40 copies: cold solve 7 -> 6, warm re-solve
     ends at index 5 -- below the window -- so the next solve starts outside it (golden G1 / G5 values of the reference)."""
     gold = golden("g1_builtin.npz")
     B = 40
     rep = lambda a: np.repeat(np.asarray(a)[None], B, axis=0)
     H, g, A, l, u = (rep(gold[k]) for k in ("H", "g", "A", "l", "u"))
-    m = _solver(H, g, A, l, u, prec, False, kernel="resident" if prec == torch.float32 else "generic")
+    m = _solver(H, g, A, l, u, prec, False, kernel="resident" if prec == torch.float32 else k64)
     assert m.get_window()[0] == 5
     r1 = m.solve()
     assert bool((r1.info.iter == int(gold["iter"])).all()) and bool((r1.info.status_code == 0).all())
@@ -145,13 +148,13 @@ def test_window_g1_chain_below_the_window(golden, prec, xtol):
     assert bool((r3.info.status_code == 0).all())
     if prec == torch.float64:
         assert bool((m.get_window()[1] < 6).all())
-    mf = _solver(H, g, A, l, u, prec, True, kernel="resident" if prec == torch.float32 else "generic")
+    mf = _solver(H, g, A, l, u, prec, True, kernel="resident" if prec == torch.float32 else k64)
     mf.solve(); mf.solve()
     r3f = mf.solve()
     assert torch.equal(r3.x, r3f.x) and torch.equal(r3.info.iter, r3f.info.iter) and torch.equal(r3.info.rho_ind, r3f.info.rho_ind)
 
 
-@pytest.mark.parametrize("prec,kernel", [(torch.float32, "resident"), (torch.float64, "generic")])
+@pytest.mark.parametrize("prec,kernel", [(torch.float32, "resident"), (torch.float64, "generic"), (torch.float64, "resident")])
 def test_window_warm_start_iterate_and_K_outside(prec, kernel):
     B, n, n_eq, n_ineq = 40, 20, 5, 35
     dt = np.float32 if prec == torch.float32 else np.float64
