@@ -250,11 +250,11 @@ int select_kernels(rqp_handle* h) {
     // have no packed copy of it; the fp16 tile IS the smaller copy)
     h->k_direct = (h->dims.flags & RQP_FLAG_LOW_MEMORY) && h->resident && h->dims.tile_dtype != RQP_TILE_F16;
     // rho-ladder window (rqp_common.h): batches of per-instance matrices whose solve kernel runs the exit-and-continue protocol
-    // (resident float32 / float64 tiles, streaming kernel).  Not with check_infeasibility (its certificate pass reads K at the final index)
+    // (resident float32 / float64 tiles, one-wavefront kernel, streaming kernel).  Not with check_infeasibility (its certificate pass reads K at the final index)
     // and not on request (RQP_FLAG_FULL_LADDER: rqp_solve then never synchronises the host, e.g. for graph capture).
     h->kwin = h->nrho;
     h->windowed = !h->dims.shared_mats && h->nmat >= 32 && h->nrho > RQP_WINDOW && !(h->dims.flags & RQP_FLAG_FULL_LADDER) &&
-                  !h->st.check_infeasibility && !h->use_mfma && !h->use_wave;
+                  !h->st.check_infeasibility && !h->use_mfma;
     if (h->windowed) h->kwin = RQP_WINDOW;
     if (h->use_mfma) h->kernel_name = h->mfmal ? "mfmal" : (h->mfma16 ? "mfma16" : "mfma");
     else if (h->use_wave) h->kernel_name = "wave";

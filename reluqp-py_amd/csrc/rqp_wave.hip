@@ -80,6 +80,31 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     const int c = NC * wv + lane % NC, h = lane / NC;                  // global column, column part
     const int r0 = MC * wv + lane;                                     // first row of this lane
     const bool cok = c < n;
+    // rho-ladder window (rqp_common.h; same protocol as k_admm_res2): K slot s of this instance holds ladder index wb + s.
+    // SolveArgs.cont = 2: only the instances that left their window (cstat = 1), resumed EXACTLY behind the check they left at.
+    int ri = a.rho_ind[b];
+    int k0 = 0;
+    bool exact = false;
+    if (a.cont == 2) {
+        if (a.cstat[b] == 0) return;
+        const int ci = a.cont_iter[b];
+        if (ci >= 0) {
+            k0 = ci;
+            exact = true;
+        }
+    }
+    const int wb = a.wbase ? a.wbase[(a.sK == 0) ? 0 : b] : 0;
+    if (a.cstat) {
+        const int sl = ri - wb;
+        if (sl < 0 || sl >= a.kwin) {                                   // (uniform) the incoming index lies outside the window: leave
+            if (threadIdx.x == 0) {                                     // untouched; rqp_solve re-centres the window and restarts it
+                a.cstat[b] = 1;
+                if (!exact) a.cont_iter[b] = -1;
+                atomicAdd(a.ncont, 1);
+            }
+            return;
+        }
+    }
     const T* A = (const T*)a.A + (size_t)b * a.sA;
     const T* At = (const T*)a.At + (size_t)b * a.sAt;
     const T* Ht = (const T*)a.Ht + (size_t)b * a.sH;
@@ -103,10 +128,9 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     for (int q = 0; q < RL; ++q) load_row(Ar[q], NCT, A + (size_t)(r0 + 64 * q) * ldn, r0 + 64 * q < m, ldn);   // row r_q of A
     load_row(Atc, AT, At + (size_t)c * ldm + AT * h, cok, ldm - AT * h);     // rows AT h .. of column c
     load_row(Hc, KH, Ht + (size_t)c * ldn + KH * h, cok, ldn - KH * h);      // sym(H): row c = column c
-    int ri = a.rho_ind[b];
     if (threadIdx.x < 32) rhoL[threadIdx.x] = ((int)threadIdx.x < a.nrho) ? (T)a.rhos[threadIdx.x] : (T)0;   // (nrho <= 32: rqp_wave_fits)
     auto load_K = [&]() __attribute__((always_inline)) {
-        load_row(Kc, KH, Kb + ((size_t)ri * n + c) * ldn + KH * h, cok, ldn - KH * h);
+        load_row(Kc, KH, Kb + ((size_t)(ri - wb) * n + c) * ldn + KH * h, cok, ldn - KH * h);
     };
     load_K();
 
@@ -205,12 +229,13 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     xL[c] = (T)x;
     handoff();
 #pragma unroll
-    for (int q = 0; q < RL; ++q) zt[q] = (double)a_times(q);
+    for (int q = 0; q < RL; ++q)                                        // (an exact continuation brought A x along)
+        zt[q] = exact ? ((r0 + 64 * q < m) ? a.ax[(size_t)b * m + r0 + 64 * q] : 0.0) : (double)a_times(q);
 
     bool converged = false;
     int iters = 0;
     T pri = (T)0, dua = (T)0, hx = (T)0;
-    T rho_est = (T)a.rhos[ri];                                          // :211
+    T rho_est = exact ? (T)a.cont_rho[b] : (T)a.rhos[ri];               // :211
     const T tolT = (T)a.tol;
     const int kmax = a.max_iter;
 
@@ -248,7 +273,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
     };
 
     int to_chk = a.check_interval;                                      // iterations until k % check_interval == 0
-    for (int k = 1; k <= kmax; ++k) {
+    for (int k = k0 + 1; k <= kmax; ++k) {                              // (k0 > 0: an exact continuation, on the check grid)
 #pragma unroll
         for (int q = 0; q < RL; ++q) {                                  // row role: lam_hat, nu
             const double p = zt[q] - z[q];
@@ -289,19 +314,41 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
                 double* tr = a.info.trace + ((size_t)b * a.info.trace_cap + (k / a.check_interval - 1)) * 4;
                 tr[0] = (double)pri; tr[1] = (double)dua; tr[2] = (double)rho_est; tr[3] = (double)ri_before;
             }
+            const T tp = a.eps_rel > 0 ? (T)a.thr_p + (T)a.eps_rel * scl_p : (T)a.thr_p;      // :233 (+ relative term, 8(f)-3)
+            const T td = a.eps_rel > 0 ? (T)a.thr_d + (T)a.eps_rel * scl_d : (T)a.thr_d;
+            if (pri < tp && dua < td) {
+                converged = true;
+                break;
+            }
             if (ri != ri_before) {                                      // "re-factor" = table lookup
+                if (a.cstat && k < kmax && (ri < wb || ri >= wb + a.kwin)) {
+                    // the new index has no K in this instance's window: leave with the exact state; rqp_solve re-factors a
+                    // window around ri and continues the instance behind this check (SolveArgs.cont = 2)
+                    if (h == 0 && cok) a.x[(size_t)b * n + c] = x;
+#pragma unroll
+                    for (int q = 0; q < RL; ++q) {
+                        const int r = r0 + 64 * q;
+                        if (r < m) {
+                            a.z[(size_t)b * m + r] = z[q];
+                            a.lam[(size_t)b * m + r] = lam[q];
+                            a.ax[(size_t)b * m + r] = zt[q];
+                        }
+                    }
+                    if (threadIdx.x == 0) {
+                        a.rho_ind[b] = ri;
+                        a.cont_iter[b] = k;
+                        a.cont_rho[b] = (double)rho_est;
+                        a.cstat[b] = 1;
+                        atomicAdd(a.ncont, 1);
+                    }
+                    return;
+                }
                 load_K();
 #pragma unroll
                 for (int q = 0; q < RL; ++q) {
                     rv[q] = (T)a.rhos[ri] * cr[q];
                     inv[q] = 1.0 / (double)rv[q];
                 }
-            }
-            const T tp = a.eps_rel > 0 ? (T)a.thr_p + (T)a.eps_rel * scl_p : (T)a.thr_p;      // :233 (+ relative term, 8(f)-3)
-            const T td = a.eps_rel > 0 ? (T)a.thr_d + (T)a.eps_rel * scl_d : (T)a.thr_d;
-            if (pri < tp && dua < td) {
-                converged = true;
-                break;
             }
         }
     }
@@ -330,6 +377,7 @@ __global__ void __launch_bounds__(64 * NWV, (WOcc<T, NC, MC, NWV>::value)) k_adm
         if (a.info.rho_estimate) a.info.rho_estimate[b] = (double)rho_est;
         if (a.info.obj_val) a.info.obj_val[b] = jp;
         a.rho_ind[b] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
+        if (a.cstat) a.cstat[b] = 0;
     }
     if (h == 0 && cok) a.x[(size_t)b * n + c] = (a.warm_starting || a.keep_state) ? x : 0.0;           // state persists (:304) or is cleared (:324-333)
 #pragma unroll

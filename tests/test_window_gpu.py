@@ -60,6 +60,11 @@ CASES = [  # (precision, kernel, n, n_eq, n_ineq, feasible, settings)
     (torch.float64, "resident", 10, 5, 15, False, dict(max_iter=600)),               # k_admm_res64
     (torch.float64, "resident", 40, 10, 70, False, dict(max_iter=400, check_interval=10)),
     (torch.float64, "resident", 100, 25, 275, True, dict(eps_abs=1e-6)),
+    (torch.float32, "wave", 10, 5, 15, False, dict(max_iter=600)),                   # k_admm_wave: one wavefront per QP
+    (torch.float64, "wave", 12, 4, 20, False, dict(max_iter=500, check_interval=10)),
+    (torch.float32, "wave", 30, 8, 100, False, dict(max_iter=400)),                  # two rows per lane
+    (torch.float32, "wave", 60, 10, 90, True, dict(eps_abs=1e-5)),                   # two wavefronts per QP
+    (torch.float32, "wave", 32, 8, 56, True, dict(eps_abs=1e-5)),                    # BASELINE config 4 shape
 ]
 
 
@@ -154,7 +159,8 @@ def test_window_g1_chain_below_the_window(golden, prec, xtol, k64):
     assert torch.equal(r3.x, r3f.x) and torch.equal(r3.info.iter, r3f.info.iter) and torch.equal(r3.info.rho_ind, r3f.info.rho_ind)
 
 
-@pytest.mark.parametrize("prec,kernel", [(torch.float32, "resident"), (torch.float64, "generic"), (torch.float64, "resident")])
+@pytest.mark.parametrize("prec,kernel", [(torch.float32, "resident"), (torch.float64, "generic"), (torch.float64, "resident"),
+                                         (torch.float32, "wave")])
 def test_window_warm_start_iterate_and_K_outside(prec, kernel):
     B, n, n_eq, n_ineq = 40, 20, 5, 35
     dt = np.float32 if prec == torch.float32 else np.float64
@@ -197,8 +203,8 @@ def test_window_rules():
     assert ms.get_window()[1] is None                                # small batches: the whole ladder
     mh = _solver(H[0], g, A[0], l, u, torch.float32, False)          # shared (H, A): one ladder for the batch
     assert mh.get_window()[1] is None
-    mv = _solver(H, g, A, l, u, torch.float32, False)                # one-wavefront kernel: no window (yet)
-    assert mv.kernel == "wave" and mv.get_window()[1] is None
+    mv = _solver(H, g, A, l, u, torch.float32, False)                # one-wavefront kernel: windowed too
+    assert mv.kernel == "wave" and mv.get_window()[0] == 5
     # a windowed solve cannot be captured into a HIP graph (it synchronises); full_ladder can
     graph = torch.cuda.CUDAGraph()
     mw.synchronous = False
