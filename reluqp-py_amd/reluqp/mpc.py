@@ -195,6 +195,14 @@ class LinearMPC(object):
         x+ = Ad x + Bd u0 = (Ad - Bd K) x + Bd v0: two GEMMs per step (Acl' and Bd' are what they multiply from the right)."""
         import torch
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device, dtype=dtype)
+        if self.form == "sparse":
+            # the reference's own form (RandomLinMPC.py:54-66): g does not depend on x0; l = u = -Ad x0 on the first dynamics
+            # block; the first input is the first nu variables, the plant step x+ = Ad x + Bd u0
+            n, m = self.H.shape[0], self.A.shape[0]
+            lumap = np.zeros((m, self.nx))
+            lumap[:self.nx] = -self.Ad
+            return dict(gmap=t(np.zeros((n, self.nx))), lumap=t(lumap), ladd=t(self.l0), uadd=t(self.u0),
+                        Aclt=t(self.Ad.T), Bdt=t(self.Bd.T))
         return dict(gmap=t(self.g_x0), lumap=t(self.lu_x0), ladd=t(self.l_add), uadd=t(self.u_add),
                     Aclt=t((self.Ad - self.Bd @ self.K).T), Bdt=t(self.Bd.T))
 
@@ -204,7 +212,6 @@ class LinearMPC(object):
         input block of the solution.  torch is used here for the caller-side plant step only; the QP path is the HIP library.
         Returns (final states [B, nx] tensor, mean ADMM iterations per solve)."""
         import torch
-        assert self.form == "condensed"
         mp = self._device_maps(device, dtype)
         x = torch.as_tensor(np.atleast_2d(x0), device=device, dtype=dtype)
         it_acc = None
@@ -235,7 +242,7 @@ class LinearMPC(object):
         and replayed ``steps`` times: no host work per step at all (launch-bound small batches gain the most).
         The solver must be set up (run simulate_device for one step first).  Returns as simulate_device."""
         import torch
-        assert self.form == "condensed" and self._ready
+        assert self._ready
         mp = self._device_maps(device, dtype)
         x = torch.as_tensor(np.atleast_2d(x0), device=device, dtype=dtype).clone()   # static buffer: rewritten in place
         it_acc = torch.zeros(x.shape[0], device=device, dtype=torch.int32)

@@ -241,6 +241,35 @@ def test_closed_loop_graph_replay_matches_eager():
     np.testing.assert_allclose(xb.cpu().numpy(), xa.cpu().numpy(), rtol=0, atol=1e-6)
 
 
+def test_closed_loop_sparse_form_on_device_matches_host_loop_and_graph():
+    """The reference's own (sparse) MPC form in closed loop: the device loop (affine x0 maps, rqp_update_affine) follows the
+    host loop (qp_vectors + update(g, l, u) per step, the path of reluqpth.py:159-183) and the HIP-graph replay; the
+    streamed-operand MFMA kernel serves it at the full config-3 shape."""
+    dev = torch.device("cuda:0")
+    B, steps = 300, 6
+    ctls = []
+    for _ in range(3):
+        Ad, Bd = mpc.random_plant(12, 4, seed=0)
+        ctls.append(mpc.LinearMPC(Ad, Bd, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="sparse", device=dev,
+                                  precision=torch.float32, eps_abs=1e-4))
+    x0 = 0.5 * np.random.RandomState(4).randn(B, 12)
+    xa, _ = ctls[0].simulate_device(x0, 1, dev, torch.float32)
+    xb, _ = ctls[1].simulate_device(x0, 1, dev, torch.float32)
+    assert ctls[0].solver.kernel == "mfmal" and torch.equal(xa, xb)
+    xa, ita = ctls[0].simulate_device(xa.cpu().numpy(), steps, dev, torch.float32)
+    xb, itb = ctls[1].simulate_graph(xb.cpu().numpy(), steps, dev, torch.float32)
+    assert abs(ita - itb) < 1e-9
+    np.testing.assert_allclose(xb.cpu().numpy(), xa.cpu().numpy(), rtol=0, atol=1e-6)
+    # host loop: step() = qp_vectors + update + warm-started solve, plant step in numpy
+    x = x0.copy()
+    for _ in range(steps + 1):
+        u0, res = ctls[2].step(x)
+        assert all(s == "solved" for s in res.info.status)
+        x = x @ ctls[2].Ad.T + u0 @ ctls[2].Bd.T
+    np.testing.assert_allclose(xa.cpu().double().numpy(), x, rtol=0, atol=2e-3 * max(1.0, np.abs(x).max()))
+    assert np.linalg.norm(x, axis=1).mean() < np.linalg.norm(x0, axis=1).mean()      # the loop regulates
+
+
 def test_solver_destroyed_during_graph_capture_keeps_the_capture_valid():
     """A solver object dies (rqp_destroy -> hipFree of its workspace) while this thread captures the control step of ANOTHER
     solver: the capture must stay valid and replay correctly (free_ws frees under the relaxed capture mode; the capture
