@@ -346,6 +346,76 @@ __global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
     }
 }
 
+// Large n (> 128: a few shared matrices, e.g. the sparse linear-MPC form n = 320): the same sweep with 1024 threads per matrix.
+// Thread (ty, tx) of a 32 x 32 grid owns the elements (ty + 32 i, tx + 32 j), i, j < RT = ceil(n / 32) <= 10: no integer division
+// in the sweep, the pivot row / column values of a step in 2 RT registers, M in the L2-resident float64 scratch slab
+// (coalesced: a wavefront touches two 256-byte row segments).  [k_factor<T, false>: 256 threads, i / n and i % n per element:
+// 30 ms for the 18 matrices of that problem; this kernel: see DESIGN.md section 5]
+template <typename T, int RT>
+__global__ void __launch_bounds__(1024) k_factor_big(SetupArgs a) {
+    __shared__ double colb[32 * RT], rowb[32 * RT];
+    __shared__ double piv;
+    const int n = a.n;
+    const int mat = blockIdx.x / a.kwin, j = blockIdx.x % a.kwin;
+    if (a.only && !a.only[mat]) return;
+    double* M = a.fscratch + (size_t)blockIdx.x * n * n;
+    const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
+    const double* G = a.G + (size_t)mat * n * n;
+    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + j];
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+#pragma unroll 1
+    for (int i = 0; i < RT; ++i) {
+        const int r = ty + 32 * i;
+        if (r >= n) break;
+        for (int q = 0; q < RT; ++q) {
+            const int c = tx + 32 * q;
+            if (c >= n) break;
+            const double hs = 0.5 * ((double)Ht[(size_t)r * a.ldn + c] + (double)Ht[(size_t)c * a.ldn + r]);
+            M[(size_t)r * n + c] = hs + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) piv = 1.0 / M[(size_t)k * n + k];
+        __syncthreads();
+        const double p = piv;
+        if (tid < n) {
+            colb[tid] = M[(size_t)tid * n + k];
+            rowb[tid] = (tid == k) ? p : M[(size_t)k * n + tid] * p;
+        }
+        __syncthreads();
+        double rb[RT];
+#pragma unroll
+        for (int q = 0; q < RT; ++q) rb[q] = rowb[tx + 32 * q];      // (entries past n: unused)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int r = ty + 32 * i;
+            if (r < n) {
+                const double cb = colb[r];
+                double* Mr = M + (size_t)r * n;
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    const int c = tx + 32 * q;
+                    if (c < n) {
+                        double v;
+                        if (r == k) v = rb[q];
+                        else if (c == k) v = -cb * p;
+                        else v = Mr[c] - cb * rb[q];
+                        Mr[c] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    T* K = (T*)a.K + ((size_t)mat * a.kwin + j) * n * a.ldn;
+    for (int i = tid; i < n * a.ldn; i += 1024) {
+        const int r = i / a.ldn, c = i % a.ldn;
+        // symmetrise the rounded result so that column-oriented products see one matrix
+        K[i] = (c < n) ? (T)(0.5 * (M[(size_t)r * n + c] + M[(size_t)c * n + r])) : T(0);
+    }
+}
+
 // Fast path for n <= 128: same in-place Gauss-Jordan, but thread t owns column c = t & (CN-1) of the row slice
 // rs = t / CN (no integer division in the sweep, row k of the step in a register, column k broadcast from LDS).
 // CN = 64 or 128 columns (power of two >= n).
@@ -556,6 +626,11 @@ hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             if (e != hipSuccess) return e;
             k_factor<double, true><<<grid, 256, lds_need, s>>>(a);
         }
+    } else if (n <= 320) {
+        if (h->esz == 4)
+            k_factor_big<float, 10><<<grid, 1024, 0, s>>>(a);
+        else
+            k_factor_big<double, 10><<<grid, 1024, 0, s>>>(a);
     } else {
         const size_t small = 2 * (size_t)n * sizeof(double);
         if (h->esz == 4)

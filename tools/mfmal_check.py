@@ -22,6 +22,7 @@ for B in [int(v) for v in (sys.argv[1:] or ["64", "4096"])]:
         for _ in range(3):
             r = m.solve(); ks.append(m.last_kernel_time * 1e3)
         out[kern] = (r.x.clone(), r.info.iter.clone(), r.info.status_code.clone(), r.info.pri_res.clone(), r.info.dua_res.clone())
+        out[kern + "_ri"] = r.info.rho_ind.clone()
         print("B=%d %-8s kernel %s ms  %.3f M QP/s  mean it %.1f max it %d solved %.3f setup %.1f ms" % (B, m.kernel, " ".join("%.3f" % k for k in ks), B / min(ks[1:]) / 1e3,
               r.info.iter.float().mean().item(), int(r.info.iter.max()), (r.info.status_code == 0).float().mean().item(), m.results.info.setup_time * 1e3), flush=True)
         del m
@@ -31,6 +32,11 @@ for B in [int(v) for v in (sys.argv[1:] or ["64", "4096"])]:
     print("   same iterations %.4f  max|dit| %d  max|dx| (same) %.2e  max|x| %.2f  nan %s  pri %.2e/%.2e dua %.2e/%.2e" % (same.float().mean().item(), int((ita - itb).abs().max()),
           float((xa - xb)[same].abs().max()) if bool(same.any()) else -1.0, float(xb.abs().max()), bool(torch.isnan(xa).any()),
           float(pa.max()), float(pb.max()), float(da.max()), float(db.max())), flush=True)
+    dxi = (xa - xb).abs().amax(1)
+    big = (dxi > 1e-3) & same
+    ria, rib = out["mfma_ri"], out["generic_ri"]
+    print("   instances with same iterations and |dx| > 1e-3: %d; of those with a different final rho index: %d; different rho index overall: %d"
+          % (int(big.sum()), int((big & (ria != rib)).sum()), int((ria != rib).sum())), flush=True)
     if B <= 64:
         from oracle import reluqp_oracle as O
         ref = O.solve_batch(ctl.H, g[:8], ctl.A, l[:8], u[:8], form="factored", eps_abs=1e-3)
