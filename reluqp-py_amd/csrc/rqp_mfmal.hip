@@ -5,12 +5,14 @@
 //
 // Same recurrence, checks, quirk dispositions and per-instance semantics as k_admm_mfma (rqp_mfma.hip; reference line citations
 // in rqp_admm.hip); the batch is again the N = 16 axis of v_mfma_f32_16x16x4_f32 (exact float32 products).  What differs:
-//   * Operands are STREAMED from L2.  The unit is a GROUP: one 16 x 16 block of a matrix = 4 MFMAs, one global_load_dwordx4 per
+//   * Operands are STREAMED from L2.  The unit is a GROUP: one 16 x 16 block of a matrix = 4 MFMAs, one buffer_load_dwordx4 per
 //     lane (1 KB per wave, lane-linear) and one ds_read_b128 of the vector operand.  Every wave walks ONE stream of groups per
 //     GEMM (its tiles back to back; a flag on a tile's last group sends the accumulator to LDS and clears it), requested
-//     ML_D = 8 groups ahead through a register ring that stays in flight across the LDS barriers (the next GEMM's first
-//     groups are requested before the current GEMM's epilogue).  GEMM1 ([A; H']' [nu; x]) and GEMM3 (A dx) stream only the
-//     NON-ZERO blocks of their matrices (k_nz_mfmal / k_meta_mfmal at setup); GEMM2 (K_j d) is dense over ceil(n / 16) blocks.
+//     ML_D - 1 = 4 groups ahead through a register ring that stays in flight across the LDS barriers (the last visits of a
+//     GEMM request the first groups of the next one).  GEMM1 ([A; H']' [nu; x]) and GEMM3 (A dx) stream only the NON-ZERO blocks
+//     of their matrices (k_nz_mfmal / k_meta_mfmal at setup); GEMM2 (K_j d) is dense over ceil(n / 16) blocks.
+//   * No vector-ALU instruction inside the visit loops (the float32 MFMA shares its lanes with the VALU: one address v_add per
+//     visit cost 38 of a visit's 128 MFMA cycles): scalar operand offsets, compile-time LDS offsets in the dense stream.
 //   * The k index of MFMA j of a group is 16 blk + 4 kq + j (kq = lane / 16): the rows a lane supplies as the B operand are the
 //     rows it holds of a D result (16 T + 4 kq + r).  Vectors live in LDS as [block][lane] float4 -- results are written and
 //     operands read as lane-linear b128 accesses, no swizzle, no bank conflicts.
@@ -786,7 +788,6 @@ hipError_t rqp_prepare_mfmal(const rqp_handle* h) {
         (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 1>, ml_lds_floats() * sizeof(float));
         (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 2>, ml_lds_floats() * sizeof(float));
         (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 3>, ml_lds_floats() * sizeof(float));
-        (void)rqp_raise_lds_limit((const void*)k_admm_mfmal<true, 4>, ml_lds_floats() * sizeof(float));
         e = rqp_raise_lds_limit((const void*)k_admm_mfmal<true>, ml_lds_floats() * sizeof(float));
     }
     return e;
@@ -802,7 +803,6 @@ hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipSt
         if (exv == 1) k_admm_mfmal<true, 1><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
         else if (exv == 2) k_admm_mfmal<true, 2><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
         else if (exv == 3) k_admm_mfmal<true, 3><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
-        else if (exv == 4) k_admm_mfmal<true, 4><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
         else k_admm_mfmal<true><<<grid, ML_NT, ml_lds_floats() * sizeof(float), s>>>(a, h->W1img, dbg);
         (void)hipStreamSynchronize(s);
         std::vector<unsigned long long> hb(cnt);
