@@ -232,9 +232,10 @@ int select_kernels(rqp_handle* h) {
                 break;
             if (rqp_mfma_fits(h) && mfma_pays)
                 h->use_mfma = true;
-            else if (rqp_mfmal_fits(h) && !rqp_res2_fits(h) && !rqp_wave_fits(h) && h->B >= 256)
+            else if (rqp_mfmal_fits(h) && !rqp_res2_fits(h) && !rqp_wave_fits(h))
                 h->use_mfma = h->mfmal = true;   // beyond every resident tile (the sparse linear-MPC form): 16-instance MFMA tiles with
                                                  // streamed operands instead of the streaming kernel's 2 MB of matrices per instance-iteration
+                                                 // (any batch: ONE instance solves in 1.0 ms against 2.8 ms, tools/mfmal_check.py 1)
             else if (rqp_wave_fits(h))       // small problems: one wavefront per instance
                 h->use_wave = true;
             else if (rqp_res2_fits(h))

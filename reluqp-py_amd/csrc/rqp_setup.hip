@@ -346,69 +346,134 @@ __global__ void __launch_bounds__(256) k_factor(SetupArgs a) {
     }
 }
 
-// Large n (> 128: a few shared matrices, e.g. the sparse linear-MPC form n = 320): the same sweep with 1024 threads per matrix.
-// Thread (ty, tx) of a 32 x 32 grid owns the elements (ty + 32 i, tx + 32 j), i, j < RT = ceil(n / 32) <= 10: no integer division
-// in the sweep, the pivot row / column values of a step in 2 RT registers, M in the L2-resident float64 scratch slab
-// (coalesced: a wavefront touches two 256-byte row segments).  [k_factor<T, false>: 256 threads, i / n and i % n per element:
-// 30 ms for the 18 matrices of that problem; this kernel: see DESIGN.md section 5]
-template <typename T, int RT>
-__global__ void __launch_bounds__(1024) k_factor_big(SetupArgs a) {
-    __shared__ double colb[32 * RT], rowb[32 * RT];
-    __shared__ double piv;
+// Large n (142 < n <= 320, e.g. the sparse linear-MPC form n = 320): BLOCKED Gauss-Jordan, 16 pivots per pass over the matrix.
+// With M = [[A, B], [C, D]] and pivot block A (16 x 16): M <- [[A^-1, A^-1 B], [-C A^-1, D - C A^-1 B]] -- exactly 16 steps of the
+// unblocked sweep of k_factor, but the matrix (float64, in the L2-resident scratch slab) is read and written ONCE per 16 pivots:
+// column panel C, row panel B and A live in LDS, the trailing update is a rank-16 product from LDS.  1024 threads per matrix,
+// thread (ty, tx) of a 32 x 32 grid owns the elements (ty + 32 a, tx + 32 b).  [k_factor<T, false>: 30 ms for the 18 matrices of the
+// sparse MPC problem; one pivot per pass with 1024 threads: 7.8 ms; this kernel: DESIGN.md section 5]
+constexpr int FB_N = 320, FB_P = 16;
+constexpr size_t fb_lds_bytes() { return ((size_t)FB_N * (FB_P + 1) + (size_t)FB_P * FB_N + (size_t)FB_P * (FB_P + 1) + 8) * sizeof(double); }
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_factor_blk(SetupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int P = FB_P, RT = FB_N / 32;
+    double* Cb = (double*)smem_raw;              // [n][P + 1]  column panel M[:, K] (before the pass)
+    double* Rb = Cb + FB_N * (P + 1);            // [P][n]      row panel M[K, :], then A^-1 M[K, :]
+    double* Pb = Rb + P * FB_N;                  // [P][P + 1]  pivot block, then its inverse
     const int n = a.n;
-    const int mat = blockIdx.x / a.kwin, j = blockIdx.x % a.kwin;
+    const int mat = blockIdx.x / a.kwin, jslot = blockIdx.x % a.kwin;
     if (a.only && !a.only[mat]) return;
     double* M = a.fscratch + (size_t)blockIdx.x * n * n;
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
-    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + j];
+    const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + jslot];
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-#pragma unroll 1
-    for (int i = 0; i < RT; ++i) {
-        const int r = ty + 32 * i;
-        if (r >= n) break;
-        for (int q = 0; q < RT; ++q) {
-            const int c = tx + 32 * q;
-            if (c >= n) break;
-            const double hs = 0.5 * ((double)Ht[(size_t)r * a.ldn + c] + (double)Ht[(size_t)c * a.ldn + r]);
-            M[(size_t)r * n + c] = hs + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
-        }
+    for (int i = tid; i < n * n; i += 1024) {
+        const int r = i / n, c = i % n;
+        const double hs = 0.5 * ((double)Ht[(size_t)r * a.ldn + c] + (double)Ht[(size_t)c * a.ldn + r]);
+        M[i] = hs + (r == c ? a.sigma : 0.0) + rho * G[i];
     }
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        if (tid == 0) piv = 1.0 / M[(size_t)k * n + k];
-        __syncthreads();
-        const double p = piv;
-        if (tid < n) {
-            colb[tid] = M[(size_t)tid * n + k];
-            rowb[tid] = (tid == k) ? p : M[(size_t)k * n + tid] * p;
+    for (int k0 = 0; k0 < n; k0 += P) {
+        const int kw = (n - k0 < P) ? (n - k0) : P;
+        // ---- panels -> LDS
+        for (int e = tid; e < n * P; e += 1024) {
+            const int i = e / P, q = e % P;                          // column panel: P consecutive doubles of row i
+            Cb[i * (P + 1) + q] = (q < kw) ? M[(size_t)i * n + k0 + q] : 0.0;
+        }
+        for (int e = tid; e < P * n; e += 1024) {
+            const int p = e / n, j = e % n;
+            Rb[p * FB_N + j] = (p < kw) ? M[(size_t)(k0 + p) * n + j] : 0.0;
+        }
+        if (tid < P * P) {
+            const int p = tid / P, q = tid % P;
+            Pb[p * (P + 1) + q] = (p < kw && q < kw) ? M[(size_t)(k0 + p) * n + k0 + q] : (p == q ? 1.0 : 0.0);
         }
         __syncthreads();
-        double rb[RT];
+        // ---- A^-1: unblocked sweep of the pivot block (threads (p, q) of a 16 x 16 grid; identity padding past kw)
+        for (int s2 = 0; s2 < P; ++s2) {
+            double nv = 0.0;
+            if (tid < P * P) {
+                const int p = tid / P, q = tid % P;
+                const double piv = 1.0 / Pb[s2 * (P + 1) + s2];
+                const double cs = Pb[p * (P + 1) + s2], rs = Pb[s2 * (P + 1) + q], cur = Pb[p * (P + 1) + q];
+                if (p == s2) nv = (q == s2) ? piv : rs * piv;
+                else nv = (q == s2) ? -cs * piv : cur - cs * (rs * piv);
+            }
+            __syncthreads();
+            if (tid < P * P) Pb[(tid / P) * (P + 1) + tid % P] = nv;
+            __syncthreads();
+        }
+        // ---- row panel: R = A^-1 M[K, :] (threads 0 .. n-1, one column each); column panel out: -C A^-1 (threads 512 ..)
+        if (tid < n) {
+            const int j = tid;
+            double rv[P];
 #pragma unroll
-        for (int q = 0; q < RT; ++q) rb[q] = rowb[tx + 32 * q];      // (entries past n: unused)
+            for (int q = 0; q < P; ++q) rv[q] = Rb[q * FB_N + j];
+            const bool inK = j >= k0 && j < k0 + kw;
+#pragma unroll 1
+            for (int p = 0; p < P; ++p) {                            // (column j is this thread's alone: written in place)
+                double s3 = 0.0;
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int r = ty + 32 * i;
-            if (r < n) {
-                const double cb = colb[r];
-                double* Mr = M + (size_t)r * n;
+                for (int q = 0; q < P; ++q) s3 = fma(Pb[p * (P + 1) + q], rv[q], s3);
+                Rb[p * FB_N + j] = inK ? Pb[p * (P + 1) + (j - k0)] : s3;   // (K columns of the K rows: A^-1)
+            }
+        } else if (tid >= 512 && tid < 512 + n) {
+            const int i = tid - 512;
+            if (i < k0 || i >= k0 + kw) {
+                double cv[P];
 #pragma unroll
-                for (int q = 0; q < RT; ++q) {
-                    const int c = tx + 32 * q;
-                    if (c < n) {
-                        double v;
-                        if (r == k) v = rb[q];
-                        else if (c == k) v = -cb * p;
-                        else v = Mr[c] - cb * rb[q];
-                        Mr[c] = v;
+                for (int q = 0; q < P; ++q) cv[q] = Cb[i * (P + 1) + q];
+#pragma unroll 1
+                for (int q2 = 0; q2 < kw; ++q2) {
+                    double s3 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) s3 = fma(cv[q], Pb[q * (P + 1) + q2], s3);
+                    M[(size_t)i * n + k0 + q2] = -s3;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- trailing update D - C R (rows outside K), rows of K <- R
+#pragma unroll 1
+        for (int a0 = 0; a0 < RT; a0 += 2) {                         // two rows of the thread at a time: 2 x 10 accumulators
+            const int i0 = ty + 32 * a0, i1 = i0 + 32;
+            if (i0 >= n) break;
+            double acc0[RT], acc1[RT];
+#pragma unroll
+            for (int b2 = 0; b2 < RT; ++b2) { acc0[b2] = 0.0; acc1[b2] = 0.0; }
+            const bool k_0 = i0 >= k0 && i0 < k0 + kw, k_1 = i1 >= k0 && i1 < k0 + kw, ok1 = i1 < n;
+            if (!(k_0 && (k_1 || !ok1))) {
+#pragma unroll 1
+                for (int p = 0; p < P; ++p) {
+                    const double c0 = Cb[i0 * (P + 1) + p], c1 = ok1 ? Cb[i1 * (P + 1) + p] : 0.0;
+#pragma unroll
+                    for (int b2 = 0; b2 < RT; ++b2) {
+                        const double r = Rb[p * FB_N + tx + 32 * b2];
+                        acc0[b2] = fma(c0, r, acc0[b2]);
+                        acc1[b2] = fma(c1, r, acc1[b2]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b2 = 0; b2 < RT; ++b2) {
+                const int j = tx + 32 * b2;
+                if (j < n) {
+                    const bool jK = j >= k0 && j < k0 + kw;
+                    if (k_0) M[(size_t)i0 * n + j] = Rb[(i0 - k0) * FB_N + j];
+                    else if (!jK) M[(size_t)i0 * n + j] -= acc0[b2];
+                    if (ok1) {
+                        if (k_1) M[(size_t)i1 * n + j] = Rb[(i1 - k0) * FB_N + j];
+                        else if (!jK) M[(size_t)i1 * n + j] -= acc1[b2];
                     }
                 }
             }
         }
         __syncthreads();
     }
-    T* K = (T*)a.K + ((size_t)mat * a.kwin + j) * n * a.ldn;
+    T* K = (T*)a.K + ((size_t)mat * a.kwin + jslot) * n * a.ldn;
     for (int i = tid; i < n * a.ldn; i += 1024) {
         const int r = i / a.ldn, c = i % a.ldn;
         // symmetrise the rounded result so that column-oriented products see one matrix
@@ -626,11 +691,16 @@ hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             if (e != hipSuccess) return e;
             k_factor<double, true><<<grid, 256, lds_need, s>>>(a);
         }
-    } else if (n <= 320) {
-        if (h->esz == 4)
-            k_factor_big<float, 10><<<grid, 1024, 0, s>>>(a);
-        else
-            k_factor_big<double, 10><<<grid, 1024, 0, s>>>(a);
+    } else if (n <= FB_N) {
+        if (h->esz == 4) {
+            e = rqp_raise_lds_limit((const void*)k_factor_blk<float>, fb_lds_bytes());
+            if (e != hipSuccess) return e;
+            k_factor_blk<float><<<grid, 1024, fb_lds_bytes(), s>>>(a);
+        } else {
+            e = rqp_raise_lds_limit((const void*)k_factor_blk<double>, fb_lds_bytes());
+            if (e != hipSuccess) return e;
+            k_factor_blk<double><<<grid, 1024, fb_lds_bytes(), s>>>(a);
+        }
     } else {
         const size_t small = 2 * (size_t)n * sizeof(double);
         if (h->esz == 4)

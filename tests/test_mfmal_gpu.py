@@ -84,20 +84,21 @@ def test_sparse_c3_full_shape_vs_streaming_kernel_oracle_and_kkt():
 
 @pytest.mark.parametrize("B", [1, 17, 255, 300])
 def test_sparse_c3_ragged_batches_and_dispatch_rule(B):
-    """Ragged last tile (padding columns), a single instance; AUTO takes the streamed-operand kernel from 256 instances."""
+    """Ragged last tile (padding columns), a single instance; AUTO takes the streamed-operand kernel at any batch size (one
+    instance: 1.0 ms against 2.8 ms on the streaming kernel)."""
     ctl, H, g, A, l, u = _c3_sparse(B, seed=3)
     mm, rm = _solve(H, g, A, l, u, kernel="mfma", eps_abs=1e-3)
     assert mm.kernel == "mfmal"
     ma, ra = _solve(H, g, A, l, u, kernel="auto", eps_abs=1e-3)
-    assert ma.kernel == ("mfmal" if B >= 256 else "generic")
+    assert ma.kernel == "mfmal"
     ref = O.solve_batch(H, g[:24], A, l[:24], u[:24], form="factored", eps_abs=1e-3)
     it = rm.info.iter.cpu().numpy()[:24]
     assert list(np.array(rm.info.status)[:24]) == ref["status"]
     assert np.mean(it == ref["iter"]) >= 0.9 and np.all(np.abs(it - ref["iter"]) <= 75)
     same = it == ref["iter"]
     np.testing.assert_allclose(rm.x.cpu().double().numpy()[:24][same], ref["x"][same], rtol=0, atol=2e-4 * max(1.0, np.abs(ref["x"]).max()))
-    if ma.kernel == "generic":
-        assert np.mean(rm.info.iter.cpu().numpy() == ra.info.iter.cpu().numpy()) >= 0.95
+    mg, rg = _solve(H, g, A, l, u, kernel="generic", eps_abs=1e-3)
+    assert mg.kernel == "generic" and np.mean(rm.info.iter.cpu().numpy() == rg.info.iter.cpu().numpy()) >= 0.95
 
 
 @pytest.mark.parametrize("n,n_eq,n_ineq", [(100, 25, 275), (150, 0, 200), (90, 13, 320), (320, 40, 600), (17, 3, 330)])
