@@ -82,6 +82,42 @@ def test_sparse_c3_full_shape_vs_streaming_kernel_oracle_and_kkt():
     assert eq.sum() == 240 and float((ra.z.cpu().double().numpy()[:, eq] - l[:, eq]).__abs__().max()) < 1e-6
 
 
+def test_more_tiles_than_cus():
+    """Three rounds of 16-instance tiles per CU and a ragged tail: every instance must come out as from the streaming kernel --
+    same iteration counts, same solution; a warm re-solve; max_iter on and off the check grid at this grid size.  (A persistent
+    grid with a refill queue was built and measured, tools/experiments/mfmal_refill_queue.patch: identical results, but slots at
+    different stages sit at different rho indices and every index costs a pass of the dense K stream -- +10 % at 65 536
+    instances, -2.5 % at 4096: not kept.)"""
+    B = 3 * 4096 + 16 * 3 + 5
+    ctl, H, g, A, l, u = _c3_sparse(B, seed=21)
+    mm, rm = _solve(H, g, A, l, u, kernel="mfma", eps_abs=1e-3)
+    mg, rg = _solve(H, g, A, l, u, kernel="generic", eps_abs=1e-3)
+    assert mm.kernel == "mfmal" and mg.kernel == "generic"
+    assert rm.info.status == rg.info.status and bool((rm.info.status_code == 0).all())
+    im, ig = rm.info.iter.cpu().numpy(), rg.info.iter.cpu().numpy()
+    assert im.min() > 0 and np.mean(im == ig) >= 0.995 and np.all(np.abs(im - ig) <= 25), (np.mean(im == ig), np.abs(im - ig).max())
+    same = im == ig
+    scale = max(1.0, float(rg.x.abs().max()))
+    # (a marginal rho move at a check changes the path but not the count: a handful of 12 000 -- compared where the indices agree)
+    same &= (rm.info.rho_ind.cpu().numpy() == rg.info.rho_ind.cpu().numpy())
+    assert same.mean() >= 0.99
+    np.testing.assert_allclose(rm.x.cpu().numpy()[same], rg.x.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.z.cpu().numpy()[same], rg.z.cpu().numpy()[same], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(rm.y.cpu().numpy()[same], rg.y.cpu().numpy()[same], rtol=0, atol=2e-3 * max(1.0, float(rg.y.abs().max())))
+    pri, dua = _kkt(H, A, g, rm)
+    assert float(pri.max()) < 1e-3 * np.sqrt(560) * 1.02 + 1e-5 and float(dua.max()) < 1e-3 * np.sqrt(320) * 1.02 + 1e-5
+    r2 = mm.solve()                                                   # warm-started: state persisted per instance
+    assert bool((r2.info.status_code == 0).all())
+    assert float(r2.info.iter.double().mean()) <= float(rm.info.iter.double().mean())
+    # max_iter on the check grid ends instances inside the persistent grid too; off the grid the tiles are static
+    for mi in (50, 60):
+        m3, r3 = _solve(H, g, A, l, u, kernel="mfma", eps_abs=1e-9, max_iter=mi, warm_starting=False)
+        assert bool((r3.info.iter == mi).all()) and bool((r3.info.status_code == 1).all())
+        if mi == 50:
+            ref = O.solve_batch(H, g[-6:], A, l[-6:], u[-6:], form="factored", eps_abs=1e-9, max_iter=mi)
+            np.testing.assert_allclose(r3.x.cpu().double().numpy()[-6:], ref["x"], rtol=0, atol=2e-4 * max(1.0, np.abs(ref["x"]).max()))
+
+
 @pytest.mark.parametrize("B", [1, 17, 255, 300])
 def test_sparse_c3_ragged_batches_and_dispatch_rule(B):
     """Ragged last tile (padding columns), a single instance; AUTO takes the streamed-operand kernel at any batch size (one
