@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                 todo &= ~__ballot(lane < 16 && ri_l == jr);
                 if (todo) jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
                 body_dense(oK0 + (unsigned)jc * (unsigned)(ML_KJ * 4), ntw2, todo ? oK0 + (unsigned)jr * (unsigned)(ML_KJ * 4) : oW3, V3);
+                if constexpr (DIAG) t_acc[10] += 1;                  // K passes (one per distinct rho index of the tile)
                 stamp(4);
 #pragma unroll
                 for (int e = 0; e < TN; ++e)
@@ -819,7 +820,7 @@ hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipSt
                 fprintf(stderr, "  %s %.1f", names[e2], tot[e2] / tot[11]);
                 it += tot[e2];
             }
-            fprintf(stderr, "  | sum %.1f\n", it / tot[11]);
+            fprintf(stderr, "  | sum %.1f  | K passes per iteration %.3f\n", it / tot[11], tot[10] / tot[11]);
         }
         return hipGetLastError();
     }
