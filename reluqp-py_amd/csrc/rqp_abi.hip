@@ -119,7 +119,8 @@ void free_ws(rqp_handle* h) {
 
 hipError_t launch_solve(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
     if (h->use_mfma && a.mode == 0)
-        return h->mfmal ? rqp_launch_solve_mfmal(h, a, s) : (h->mfma16 ? rqp_launch_solve_mfma16(h, a, s) : rqp_launch_solve_mfma(h, a, s));
+        return h->mfmad ? rqp_launch_solve_mfmad(h, a, s)
+                        : (h->mfmal ? rqp_launch_solve_mfmal(h, a, s) : (h->mfma16 ? rqp_launch_solve_mfma16(h, a, s) : rqp_launch_solve_mfma(h, a, s)));
     if (h->use_wave && a.mode == 0) return rqp_launch_solve_wave(h, a, s);
     if (h->resident) return rqp_launch_solve_res2(h, a, s);
     if (h->resident64) return rqp_launch_solve_res64(h, a, s);
@@ -193,7 +194,7 @@ int select_kernels(rqp_handle* h) {
         if (req != RQP_KERNEL_RESIDENT && !((req == RQP_KERNEL_MFMA || req == RQP_KERNEL_AUTO) && mfma_ok))
             return fail_unsupported(h, "tile_dtype = f16 needs the resident kernel (float32, n <= 104, m <= 320) or the MFMA kernel");
     }
-    h->resident = h->resident64 = h->use_wave = h->use_mfma = h->mfma16 = h->mfmal = false;
+    h->resident = h->resident64 = h->use_wave = h->use_mfma = h->mfma16 = h->mfmal = h->mfmad = false;
     h->kernel_name = "generic";
     if (h->dims.tile_dtype == RQP_TILE_BF16) {     // the bf16-plane tile exists in the MFMA kernel only: an explicit request for it
         if (!rqp_mfma_fits(h) || (req != RQP_KERNEL_AUTO && req != RQP_KERNEL_MFMA))
@@ -216,7 +217,9 @@ int select_kernels(rqp_handle* h) {
         case RQP_KERNEL_MFMA:
             if (rqp_mfma_fits(h)) h->use_mfma = true;                         // operands resident in registers
             else if (rqp_mfmal_fits(h) && !h->mfma16) h->use_mfma = h->mfmal = true;   // operands streamed from L2 (rqp_mfmal.hip)
-            else return fail_unsupported(h, "kernel=mfma: needs float32, shared (H, A), n <= 320, m <= 640 (bf16 tile: n <= 80, m <= 320)");
+            else if (rqp_mfmad_fits(h) && !h->mfma16) h->use_mfma = h->mfmad = true;   // float64 MFMA, streamed operands (rqp_mfmad.hip)
+            else return fail_unsupported(h, "kernel=mfma: needs shared (H, A) and float32 with n <= 320, m <= 640 (bf16 tile: n <= 80, m <= 320) "
+                                            "or float64 with n <= 160, m <= 320");
             break;
         default: {
             // shared-(H,A) batches large enough to fill the chip with 16-instance tiles go to the MFMA kernel: from ~2k
@@ -236,6 +239,10 @@ int select_kernels(rqp_handle* h) {
                 h->use_mfma = h->mfmal = true;   // beyond every resident tile (the sparse linear-MPC form): 16-instance MFMA tiles with
                                                  // streamed operands instead of the streaming kernel's 2 MB of matrices per instance-iteration
                                                  // (any batch: ONE instance solves in 1.0 ms against 2.8 ms, tools/mfmal_check.py 1)
+            else if (rqp_mfmad_fits(h) && ((mfma_pays && h->B >= 3072) || (!rqp_res64_fits(h) && !rqp_wave_fits(h))))
+                h->use_mfma = h->mfmad = true;   // float64 shared batches: 16-instance tiles on v_mfma_f64_16x16x4_f64 from ~3k instances
+                                                 // (measured on the condensed-MPC shape: 4096 -> 1.5x the float64 resident kernel; at
+                                                 // 2048 one resident instance per CU still wins), or whenever no resident kernel fits
             else if (rqp_wave_fits(h))       // small problems: one wavefront per instance
                 h->use_wave = true;
             else if (rqp_res2_fits(h))
@@ -257,7 +264,7 @@ int select_kernels(rqp_handle* h) {
     h->windowed = !h->dims.shared_mats && h->nmat >= 32 && h->nrho > RQP_WINDOW && !(h->dims.flags & RQP_FLAG_FULL_LADDER) &&
                   !h->st.check_infeasibility && !h->use_mfma;
     if (h->windowed) h->kwin = RQP_WINDOW;
-    if (h->use_mfma) h->kernel_name = h->mfmal ? "mfmal" : (h->mfma16 ? "mfma16" : "mfma");
+    if (h->use_mfma) h->kernel_name = h->mfmad ? "mfmad" : (h->mfmal ? "mfmal" : (h->mfma16 ? "mfma16" : "mfma"));
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
     else if (h->resident64) h->kernel_name = "resident64";
@@ -286,12 +293,12 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
         if (!h->W1img) {
-            const size_t elems = h->mfmal ? rqp_mfmal_img_elems(h) : (h->mfma16 ? rqp_mfma16_img_elems(h) : rqp_mfma_img_elems(h));
+            const size_t elems = h->mfmad ? rqp_mfmad_img_elems(h) : (h->mfmal ? rqp_mfmal_img_elems(h) : (h->mfma16 ? rqp_mfma16_img_elems(h) : rqp_mfma_img_elems(h)));
             HIP_TRY(h, hipMalloc((void**)&h->W1img, elems * sizeof(float)));
             HIP_TRY(h, hipMalloc((void**)&h->queue, sizeof(int)));
-            HIP_TRY(h, h->mfmal ? rqp_prepare_mfmal(h) : (h->mfma16 ? rqp_prepare_mfma16(h) : rqp_prepare_mfma(h)));
+            HIP_TRY(h, h->mfmad ? rqp_prepare_mfmad(h) : (h->mfmal ? rqp_prepare_mfmal(h) : (h->mfma16 ? rqp_prepare_mfma16(h) : rqp_prepare_mfma(h))));
         }
-        HIP_TRY(h, h->mfmal ? rqp_launch_pack_mfmal(h, s) : (h->mfma16 ? rqp_launch_pack_mfma16(h, s) : rqp_launch_pack_mfma(h, s)));
+        HIP_TRY(h, h->mfmad ? rqp_launch_pack_mfmad(h, s) : (h->mfmal ? rqp_launch_pack_mfmal(h, s) : (h->mfma16 ? rqp_launch_pack_mfma16(h, s) : rqp_launch_pack_mfma(h, s))));
     }
     return RQP_OK;
 }

@@ -56,6 +56,7 @@ struct rqp_handle {
     bool use_mfma = false;        // rqp_mfma.hip: shared-(H,A) batches, solve() only
     bool mfma16 = false;          // ... on the bf16 matrix pipe (rqp_mfma16.hip, tile_dtype = RQP_TILE_BF16)
     bool mfmal = false;           // ... large / sparse problems, operands streamed from L2 (rqp_mfmal.hip: n <= 320, m <= 640)
+    bool mfmad = false;           // ... the same in float64 on v_mfma_f64_16x16x4_f64 (rqp_mfmad.hip: n <= 160, m <= 320)
     float* W1img = nullptr;       // lane-linear MFMA operand images ([A; H'], A, K_j)
     int* queue = nullptr;         // next-instance counter of the persistent MFMA grid
     int32_t* flag_d = nullptr;    // device scratch flag (setup-time validation)
@@ -198,6 +199,11 @@ size_t rqp_mfmal_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfmal(const rqp_handle* h, hipStream_t s);
 hipError_t rqp_prepare_mfmal(const rqp_handle* h);
 hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
+bool rqp_mfmad_fits(const rqp_handle* h);
+size_t rqp_mfmad_img_elems(const rqp_handle* h);
+hipError_t rqp_launch_pack_mfmad(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_prepare_mfmad(const rqp_handle* h);
+hipError_t rqp_launch_solve_mfmad(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 // the same kernel on the bf16 matrix pipe (rqp_mfma16.hip; rqp_dims.tile_dtype = RQP_TILE_BF16): same shapes as rqp_mfma_fits
 size_t rqp_mfma16_img_elems(const rqp_handle* h);
 hipError_t rqp_launch_pack_mfma16(const rqp_handle* h, hipStream_t s);
