@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (f32 in / f32 acc) dense peak
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: vector fp64 peak
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec: fp64 matrix (v_mfma_f64_16x16x4_f64) = the vector fp64 rate on this part
 BF16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the sparsity figure is twice that: never priced against)
 
 
@@ -379,16 +380,17 @@ def main():
             roof = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                     "note": "dense algorithmic flops 2n^2+4mn per instance-iteration; the kernel skips all-zero operand groups of the "
                             "block-triangular MPC matrices, so it executes fewer"}
-        elif kernel == "mfmal":
+        elif kernel in ("mfmal", "mfmad"):
             # streamed-operand MFMA kernel: the work is the NON-ZERO 16 x 16 blocks of A (twice: A' nu and A dx) and H plus the
             # dense K -- 512 flops per block and instance-iteration (every block is 4 v_mfma_f32_16x16x4_f32 over 16 instances)
             bl = 2 * blocks[0] + blocks[1] + blocks[2]
             tfb = rank_iters_max * bl * 512.0 / kern_avg_s / 1e12
-            roof = {"bound": "mfma", "achieved": tfb, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfb / FP32_MFMA_PEAK_TFLOPS,
+            mpeak = FP32_MFMA_PEAK_TFLOPS if kernel == "mfmal" else FP64_MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "achieved": tfb, "peak": mpeak, "unit": "TFLOP/s", "frac": tfb / mpeak,
                     "note": "block-sparse algorithmic flops: 512 per non-zero 16x16 block of A (x2), H and the dense K = %d blocks per "
                             "instance-iteration (the dense count 2n^2+4mn would be %.1fx that); operands stream from L2, "
-                            "1 KB per block and 16 instances" % (bl, f_iter / (bl * 512.0)),
-                    "blocks_per_iteration": bl, "l2_operand_gbs": rank_iters_max / 16.0 * bl * 1024.0 / kern_avg_s / 1e9}
+                            "%d KB per block and 16 instances" % (bl, f_iter / (bl * 512.0), esz // 4),
+                    "blocks_per_iteration": bl, "l2_operand_gbs": rank_iters_max / 16.0 * bl * 256.0 * esz / kern_avg_s / 1e9}
         elif kernel == "mfma16":
             # three bf16 MFMAs per product term pair: the executed matrix flops are 3x the algorithmic ones; priced in ALGORITHMIC
             # flops against the dense bf16 matrix peak (the kernel is bound by its VALU / LDS phases, not by this roof)

@@ -62,7 +62,8 @@ enum rqp_kernel {
     RQP_KERNEL_RESIDENT = 2,  /* A, K in VGPRs, one workgroup per instance (f32; f64 tile) */
     RQP_KERNEL_WAVE = 3,      /* one wavefront per instance, small problems                */
     RQP_KERNEL_MFMA = 4       /* shared (H, A), f32: batch on the MFMA N axis -- operands in registers (n <= 80,
-                               * m <= 320), else streamed from L2 as non-zero 16 x 16 blocks (n <= 320, m <= 640)  */
+                               * m <= 320), else streamed from L2 as non-zero 16 x 16 blocks (n <= 320, m <= 640);
+                               * f64: streamed operands on v_mfma_f64_16x16x4_f64 (n <= 160, m <= 320)              */
 };
 
 enum rqp_error {
