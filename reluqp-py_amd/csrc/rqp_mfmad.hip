@@ -30,7 +30,8 @@ constexpr int MD_LAST = 1 << 16, MD_NULL = 1 << 17;               // stream entr
 
 // image layout (4-byte words; a float64 operand is 2 words).  A stream entry: blk | tile << 8 | MD_LAST (last group of the tile);
 // streams are padded to multiples of MD_D groups with MD_NULL entries.
-//   meta  int [32]              : ng1[8], ng3[8], ng2[8] (padded group counts of wave w's streams), [24] blocks per tile of stream 2
+//   meta  int [64]              : ng1[8], ng3[8], ng2[8] (padded group counts of wave w's streams), [24] blocks per tile of stream 2,
+//                                 [32 + w TN + e] the e-th n tile of wave w (99: none) -- tiles are dealt longest-first over the SIMDs
 //   kb    int [8][TB]           : what the solve kernel reads (copied to LDS): one byte per group, blk | 0x40 last | 0x80 null
 //   kx1   int [8][CAP1]   kx3 int [8][CAP3]   kx2 int [8][CAP2]   (setup only: the entries with their tiles, for k_pack_mfmad)
 //   nzf   int [NB * KB1 + MB * KB2]   non-zero flags of the 16 x 16 blocks (setup scratch)
@@ -38,7 +39,7 @@ constexpr int MD_LAST = 1 << 16, MD_NULL = 1 << 17;               // stream entr
 //   W3    f64 [8][CAP3][64][4]  A[16 T + i16][16 blk + kq + 4 j]
 //   K     f64 [nrho][8][CAP2][64][4]   K_j[16 t + i16][16 blk + kq + 4 j]
 constexpr int MD_TB1 = 2 * (MD_CAP1 / MD_D) + 4, MD_TB3 = 2 * (MD_CAP3 / MD_D) + 4, MD_TB = MD_TB1 + MD_TB3;   // byte tables (dwords)
-constexpr size_t MD_OFF_KB = 32;                                   // kb [8][TB]: stream 1 | stream 3 of wave w: 8 BYTES per block of 5 groups
+constexpr size_t MD_OFF_KB = 64;                                   // kb [8][TB]: stream 1 | stream 3 of wave w: 8 BYTES per block of 5 groups
 constexpr size_t MD_OFF_KX1 = MD_OFF_KB + 8 * MD_TB, MD_OFF_KX3 = MD_OFF_KX1 + 8 * MD_CAP1, MD_OFF_KX2 = MD_OFF_KX3 + 8 * MD_CAP3;
 constexpr size_t MD_OFF_NZ = MD_OFF_KX2 + 8 * MD_CAP2;
 constexpr size_t MD_NNZ = (size_t)MD_NB * MD_KB1 + (size_t)MD_MB * MD_KB2;
@@ -98,6 +99,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
     const int* tab1 = tabs + wave_u * MD_TB;
     const int* tab3 = tab1 + MD_TB1;
     const int nb5 = __builtin_amdgcn_readfirstlane(meta[24]);       // blocks per tile of the dense stream (a multiple of D)
+    int tN[TN];                                                      // this wave's n tiles (99: none): dealt longest-first at setup
+#pragma unroll
+    for (int e = 0; e < TN; ++e) tN[e] = __builtin_amdgcn_readfirstlane(meta[32 + wave_u * TN + e]);
     for (int i = lane; i < MD_TB; i += 64) tabs[wave_u * MD_TB + i] = meta[MD_OFF_KB + wave_u * MD_TB + i];
     // (lv: the lane number through an opaque copy per loop iteration -- hipcc otherwise hoists every (array, tile) address of
     //  the unrolled state code out of the solve loop and spills them)
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
         }
 #pragma unroll
     for (int e = 0; e < TN; ++e) {
-        const int t = wave_u + NW * e;
+        const int t = tN[e];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + kq + 4 * r;
@@ -164,10 +168,10 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
 #pragma unroll
         for (int j = 0; j < D - 1; ++j) fetch(j, off);
     };
-    auto body = [&](unsigned offX, int ng, unsigned offY, const int* tab, const f64x4* Bv, f64x4* Out) __attribute__((always_inline)) {
+    auto body = [&](unsigned offX, int ng, unsigned offY, const int* tab, const f64x4* Bv, f64x4* Out, int ta, int tb, int tc) __attribute__((always_inline)) {
         f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0}, acc2 = acc;
         int kA = __builtin_amdgcn_readfirstlane(tab[0]), kB = __builtin_amdgcn_readfirstlane(tab[1]), kN = __builtin_amdgcn_readfirstlane(tab[2]);
-        int tile = wave_u;
+        int tile = ta;                                               // (the stream's tiles: ta, tb, tc)
         f64x4 bn = Bv[(kA & 63) * 64 + lv];                          // the vector operand is read one visit ahead
         auto block = [&](int g0, bool own) __attribute__((always_inline)) {
             const int q = (g0 / D) * 2;
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                     Out[tile * 64 + lv] = acc + acc2;
                     acc = (f64x4){0.0, 0.0, 0.0, 0.0};
                     acc2 = acc;
-                    tile += NW;
+                    tile = (tile == ta) ? tb : tc;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
     // of a chunk of 5 is read at the end of the chunk before it -- both candidates (the next chunk's, and block 0 for a new tile)
     auto body_dense = [&](unsigned offX, int ntw, unsigned offY, f64x4* Out) __attribute__((always_inline)) {
         f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0}, acc2 = acc;
-        int tile = wave_u;
+        int tile = tN[0];
         int left = ntw * (nb5 / D);                                  // chunks to go
         unsigned px = offX;
         f64x4 bw = DV[lv], bc = bw;
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
             Out[tile * 64 + lv] = acc + acc2;
             acc = (f64x4){0.0, 0.0, 0.0, 0.0};
             acc2 = acc;
-            tile += NW;
+            tile = tN[TN - 1];
         }
     };
     const int ntw2 = ng2 / nb5;
@@ -307,15 +311,15 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 todo = __ballot(lane < 16);
                 jr = __builtin_amdgcn_readlane(ri_l, __ffsll((long long)todo) - 1);
             }
-            body(oW1, ng1, ph == 1 ? (ntw2 ? oK0 + (unsigned)jr * (unsigned)(MD_KJ * 4) : oW3) : oW1, tab1, V1, ph == 3 ? V3 : DV);
+            body(oW1, ng1, ph == 1 ? (ntw2 ? oK0 + (unsigned)jr * (unsigned)(MD_KJ * 4) : oW3) : oW1, tab1, V1, ph == 3 ? V3 : DV, tN[0], tN[TN - 1], 0);
             stamp(1);
             if (ph == 1) {
 #pragma unroll
                 for (int e = 0; e < TN; ++e)                         // d = H x + g + A' nu
-                    if (wave_u + NW * e < NB) {
-                        f64x4 d = DV[(wave_u + NW * e) * 64 + lv];
+                    if (tN[e] < NB) {
+                        f64x4 d = DV[tN[e] * 64 + lv];
                         d[0] += gs[e][0]; d[1] += gs[e][1]; d[2] += gs[e][2]; d[3] += gs[e][3];
-                        DV[(wave_u + NW * e) * 64 + lv] = d;
+                        DV[tN[e] * 64 + lv] = d;
                     }
             }
             stamp(2);
@@ -336,8 +340,8 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 stamp(4);
 #pragma unroll
                 for (int e = 0; e < TN; ++e)
-                    if (wave_u + NW * e < NB) {
-                        const f64x4 v = V3[(wave_u + NW * e) * 64 + lv];
+                    if (tN[e] < NB) {
+                        const f64x4 v = V3[tN[e] * 64 + lv];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sel[e][r] = (first_pass || mine) ? v[r] : sel[e][r];
                     }
@@ -346,7 +350,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
             }
 #pragma unroll
             for (int e = 0; e < TN; ++e) {
-                const int t = wave_u + NW * e;
+                const int t = tN[e];
                 if (t < NB) {
                     f64x4 dx, xv;
 #pragma unroll
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
             const bool upd = (ph == 1);
             const bool fin_next = upd && (k + 1 >= kmax) && (to_chk != 1);
             const bool with_nu = upd && to_chk != 1 && !fin_next;
-            body(oW3, ng3, oW1, tab3, V3, AD);
+            body(oW3, ng3, oW1, tab3, V3, AD, wave_u, wave_u + NW, wave_u + 2 * NW);
             stamp(7);
 #pragma unroll
             for (int tl = 0; tl < TM; ++tl) {
@@ -438,7 +442,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 }
 #pragma unroll
                 for (int e = 0; e < TN; ++e)
-                    if (wave_u + NW * e < NB) V1[(MB + wave_u + NW * e) * 64 + lv] = (f64x4){0.0, 0.0, 0.0, 0.0};
+                    if (tN[e] < NB) V1[(MB + tN[e]) * 64 + lv] = (f64x4){0.0, 0.0, 0.0, 0.0};
                 ph = 2;
             }
         } else if (ph == 2) {                            // (A' lam is in DV) ; V1 = [0; x]
@@ -447,7 +451,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 if (wave_u + NW * tl < MB) V1[(wave_u + NW * tl) * 64 + lv] = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < TN; ++e)
-                if (wave_u + NW * e < NB) V1[(MB + wave_u + NW * e) * 64 + lv] = (f64x4){xs[e][0], xs[e][1], xs[e][2], xs[e][3]};
+                if (tN[e] < NB) V1[(MB + tN[e]) * 64 + lv] = (f64x4){xs[e][0], xs[e][1], xs[e][2], xs[e][3]};
             ph = 3;
         } else {                                         // ph == 3: residuals and decisions (H x is in V3, A' lam in DV)
             double w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, jp = 0.0;
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 asm volatile("" : "+v"(kq_o));                       // (keeps the rare per-row address arithmetic inside the branch)
 #pragma unroll
                 for (int e = 0; e < TN; ++e) {
-                    const int t = wave_u + NW * e;
+                    const int t = tN[e];
                     if (t < NB) {
                         const f64x4 t2v = V3[t * 64 + lv], t3v = DV[t * 64 + lv];
 #pragma unroll
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmad(SolveArgs a, const int* _
                 for (int e = 0; e < TN; ++e)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int t = wave_u + NW * e, row = 16 * t + kq_o + 4 * r;
+                        const int t = tN[e], row = 16 * t + kq_o + 4 * r;
                         if (t < NB && row < n) {
                             const size_t o = (size_t)id_o * n + row;
                             if (a.out_x) ((double*)a.out_x)[o] = xs[e][r];
@@ -637,12 +641,33 @@ __global__ void k_meta_mfmad(int n, int m, int* __restrict__ img) {
     int* meta = img;
     const int* nzf = meta + MD_OFF_NZ;
     const int w = threadIdx.x;
-    if (w >= MD_NW) return;
     const int nbt = (n + 15) / 16;
+    // n tiles are dealt to the waves longest-first (by their GEMM1 group counts) in snake order over the SIMDs -- waves w and w + 4
+    // share a SIMD: ranks 0..3 -> waves 0..3, ranks 4..7 -> waves 7..4 (largest beside smallest), the next round reversed
+    if (w == 0) {
+        int cnt[MD_NB], ord[MD_NB];
+        for (int t = 0; t < MD_NB; ++t) {
+            int c = 0;
+            for (int blk = 0; blk < MD_KB1; ++blk) c += nzf[t * MD_KB1 + blk] != 0;
+            cnt[t] = c;
+            ord[t] = t;
+        }
+        for (int i = 1; i < MD_NB; ++i)                              // (stable insertion sort, descending)
+            for (int q = i; q > 0 && cnt[ord[q]] > cnt[ord[q - 1]]; --q) { const int tmp = ord[q]; ord[q] = ord[q - 1]; ord[q - 1] = tmp; }
+        for (int i = 0; i < MD_NW * MD_TN; ++i) meta[32 + i] = 99;
+        for (int r = 0; r < MD_NB; ++r) {
+            const int round = r / MD_NW, pos2 = r % MD_NW;
+            int wv = pos2 < 4 ? pos2 : 11 - pos2;                    // 0 1 2 3 7 6 5 4
+            if (round & 1) wv = MD_NW - 1 - wv;
+            meta[32 + wv * MD_TN + round] = ord[r];
+        }
+    }
+    __syncthreads();
+    if (w >= MD_NW) return;
     int* kx = meta + MD_OFF_KX1 + w * MD_CAP1;
     int pos = 0;
     for (int e = 0; e < MD_TN; ++e) {
-        const int t = w + MD_NW * e;
+        const int t = meta[32 + w * MD_TN + e];
         if (t >= MD_NB) break;
         const int first = pos;
         for (int blk = 0; blk < MD_KB1; ++blk)
@@ -669,7 +694,7 @@ __global__ void k_meta_mfmad(int n, int m, int* __restrict__ img) {
     pos = 0;
     const int nb5 = (nbt + MD_D - 1) / MD_D * MD_D;
     for (int e = 0; e < MD_TN; ++e) {                                 // K_j is dense: nb5 blocks for each tile of the problem's own n
-        const int t = w + MD_NW * e;
+        const int t = meta[32 + w * MD_TN + e];                       // (real tiles rank before the all-zero ones: they come first)
         if (t >= nbt) break;
         for (int blk = 0; blk < nb5; ++blk) kx[pos++] = blk | (t << 8) | (blk >= nbt ? MD_NULL : 0);
     }
