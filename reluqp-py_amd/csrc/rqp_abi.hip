@@ -423,6 +423,8 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
+    if ((h->mfmal || h->mfmad) && h->B > 16)       // slot order of the streamed-operand MFMA kernels (grouped by starting rho index)
+        HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
     if (!h->use_mfma && h->B >= (h->resident64 ? 2 : 4) * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));
@@ -602,7 +604,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     a.out_x = x; a.out_z = z; a.out_lam = lam;
     if (info) a.info = *info;
     if (a.info.trace && a.info.trace_cap < 1) return fail_arg(h, "rqp_solve: trace without capacity");
-    if (h->order_d && h->use_history) {
+    if (h->order_d && h->last_iter_d && h->use_history) {
         a.order = h->order_valid ? h->order_d : nullptr;
         a.last_iter = h->last_iter_d;
     }
@@ -634,7 +636,7 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
         c.last_iter = nullptr;
         HIP_TRY(h, rqp_launch_solve_res2(h, c, s));
     }
-    const bool ranks = h->order_d && h->use_history;   // rank the instances by what they just needed: next launch goes longest-first
+    const bool ranks = h->order_d && h->last_iter_d && h->use_history;   // rank the instances by what they just needed: next launch goes longest-first
     if (h->windowed) {
         // instances whose rho index left their window stopped with their exact state: new windows, then they continue
         // (at most one window move per `RQP_WINDOW / 2` index moves, i.e. per >= 2 checks of an instance).  The ranking is

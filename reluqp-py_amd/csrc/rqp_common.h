@@ -167,6 +167,7 @@ hipError_t rqp_launch_scale_vecs(const rqp_handle* h, void* g, void* l, void* u,
 hipError_t rqp_launch_scale_state(const rqp_handle* h, double* x, double* z, double* lam, hipStream_t s);
 hipError_t rqp_launch_unscale_out(const rqp_handle* h, void* x, void* z, void* lam, double* obj, hipStream_t s);
 hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s);
+hipError_t rqp_launch_order_by(const rqp_handle* h, const int32_t* key, hipStream_t s);
 hipError_t rqp_launch_get_K(const rqp_handle* h, const void* Kmat, void* out, hipStream_t s);
 hipError_t rqp_launch_rewindow(const rqp_handle* h, int all, hipStream_t s);
 

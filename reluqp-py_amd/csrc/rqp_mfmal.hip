@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     float* red = (float*)AD;                 // [NW][16][4] row-side maxima per (wave, instance)   (phase 3 runs no GEMM3: AD is free)
     float* rr = red + NW * 16 * 4;           // [NW * 4][16][8] column-side maxima per (wave, kq, instance)
     float* rhosf = (float*)(AD + MB * 64);   // [64]
-    float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 4 rho index, 5 done
+    float* inst = rhosf + 64;                // [8][16]: 0 rho_est, 2 instance, 4 rho index, 5 done
     int* inst_i = (int*)inst;
     int* tabs = (int*)(inst + 8 * 16);       // [NW][TB] this wave's stream tables (bytes)
 
@@ -101,8 +101,11 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int id = blockIdx.x * 16 + i16;                    // this lane's instance (MFMA column)
-    const bool real = id < a.B;
+    // slot -> instance: SolveArgs.order groups the instances by the rho index they START at (every distinct index among a tile's
+    // columns is one more pass over the dense K stream; warm-started batches arrive with their persisted indices)
+    const int slot = blockIdx.x * 16 + i16;                  // this lane's slot (MFMA column)
+    const bool real = slot < a.B;
+    const int id = real ? (a.order ? a.order[slot] : slot) : 0;
     const int kmax = a.max_iter;
     const int* meta = (const int*)img;
     const int ng1 = __builtin_amdgcn_readfirstlane(meta[wave_u]), ng3 = __builtin_amdgcn_readfirstlane(meta[8 + wave_u]);
@@ -123,9 +126,12 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     // ---- scalars
     for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
     if (tid < 16) {
-        const int idt = blockIdx.x * 16 + tid;
-        const bool ok = idt < a.B;
-        const int ri = a.rho_ind[ok ? idt : blockIdx.x * 16];      // padding columns mirror the tile's first instance
+        const int st = blockIdx.x * 16 + tid;
+        const bool ok = st < a.B;
+        const int s0 = ok ? st : blockIdx.x * 16;                  // padding columns mirror the tile's first instance
+        const int idt = a.order ? a.order[s0] : s0;
+        const int ri = a.rho_ind[idt];
+        inst_i[2 * 16 + tid] = idt;
         inst_i[4 * 16 + tid] = ri;
         inst_i[5 * 16 + tid] = ok ? 0 : 1;                         // padding columns start "done"
         inst[0 * 16 + tid] = (float)a.rhos[ri];                    // rho_est = rhos[rho_ind]  (:211)
@@ -551,7 +557,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                     }
                     inst[0 * 16 + j] = est;
                     inst_i[4 * 16 + j] = ri;
-                    const int idj = blockIdx.x * 16 + j;
+                    const int idj = inst_i[2 * 16 + j];
                     const int chk_no = k / a.check_interval;
                     if (!final_chk && a.info.trace && chk_no <= a.info.trace_cap) {
                         double* tr = a.info.trace + ((size_t)idj * a.info.trace_cap + (chk_no - 1)) * 4;
@@ -793,8 +799,14 @@ hipError_t rqp_prepare_mfmal(const rqp_handle* h) {
     }
     return e;
 }
-hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a0, hipStream_t s) {
     const int grid = (h->B + 15) / 16;
+    SolveArgs a = a0;
+    if (grid > 1 && h->order_d) {                // slots grouped by the rho index the instances start at (k_order_lpt: a counting sort)
+        hipError_t e = rqp_launch_order_by(h, h->rho_ind, s);
+        if (e != hipSuccess) return e;
+        a.order = h->order_d;
+    }
     if (h->debug & 2) {          // diagnostic build: per-segment tick shares of the iteration (synchronous, debug only)
         unsigned long long* dbg = nullptr;
         const size_t cnt = (size_t)grid * ML_NW * 12;

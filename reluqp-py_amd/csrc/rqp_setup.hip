@@ -787,6 +787,12 @@ __global__ void __launch_bounds__(1024) k_order_lpt(int B, const int32_t* __rest
     for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[NBK - 1 - min(max(last_iter[i], 0), NBK - 1)], 1)] = i;
 }
 
+// the same counting sort on another key (the streamed-operand MFMA kernels group their slots by rho index)
+hipError_t rqp_launch_order_by(const rqp_handle* h, const int32_t* key, hipStream_t s) {
+    k_order_lpt<<<1, 1024, 0, s>>>(h->B, key, h->order_d);
+    return hipGetLastError();
+}
+
 hipError_t rqp_launch_order_lpt(const rqp_handle* h, hipStream_t s) {
     k_order_lpt<<<1, 1024, 0, s>>>(h->B, h->last_iter_d, h->order_d);
     return hipGetLastError();
