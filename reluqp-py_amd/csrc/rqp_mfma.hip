@@ -160,9 +160,13 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
     // ---- per-instance scalars and vectors -----------------------------------------------------------------------
     for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
     if (tid < 16) {
-        const int id = blockIdx.x * 16 + tid;
-        const bool ok = id < a.B;
-        const int ri = a.rho_ind[ok ? id : blockIdx.x * 16];       // padding columns mirror the tile's first instance (no extra K block)
+        // slot -> instance: SolveArgs.order groups the instances by the rho index they START at (every distinct index among a
+        // tile's columns is one more K pass; warm-started batches arrive with their persisted indices)
+        const int st = blockIdx.x * 16 + tid;
+        const bool ok = st < a.B;
+        const int s0 = ok ? st : blockIdx.x * 16;                  // padding columns mirror the tile's first instance (no extra K block)
+        const int id = ok ? (a.order ? a.order[st] : st) : a.B;
+        const int ri = a.rho_ind[a.order ? a.order[s0] : s0];
         inst_i[2 * 16 + tid] = id;
         inst_i[3 * 16 + tid] = 0;
         inst_i[4 * 16 + tid] = ri;
@@ -717,8 +721,9 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma(SolveArgs a, const float* 
                         }
                         a.rho_ind[bj] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
                         if (refill) {                    // this slot takes the next unsolved instance
-                            const int nxt = (int)gridDim.x * 16 + atomicAdd(queue, 1);
-                            if (nxt < a.B) {
+                            const int nsl = (int)gridDim.x * 16 + atomicAdd(queue, 1);
+                            if (nsl < a.B) {
+                                const int nxt = a.order ? a.order[nsl] : nsl;
                                 const int rn = a.rho_ind[nxt];
                                 inst_i[2 * 16 + j] = nxt;
                                 inst_i[3 * 16 + j] = k;
@@ -911,10 +916,16 @@ hipError_t rqp_prepare_mfma(const rqp_handle* h) {
         e = rqp_raise_lds_limit((const void*)k_admm_mfma<CfgM55, true>, (size_t)lds);
     return e;
 }
-hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a0, hipStream_t s) {
     const size_t lds = CfgM55::lds_floats() * sizeof(float);
     hipError_t e;
     const int tiles = (h->B + 15) / 16;
+    SolveArgs a = a0;
+    if (tiles > 1 && h->order_d && a.cont == 0) {    // slots grouped by the rho index the instances start at (one K pass per distinct index)
+        e = rqp_launch_order_by(h, h->rho_ind, s);
+        if (e != hipSuccess) return e;
+        a.order = h->order_d;
+    }
     // More tiles than CUs (one workgroup per CU: 150 KB of LDS, up to 512 registers per lane): persistent grid, slots
     // refill from a queue.  (The refill needs every exit to fall on a check, i.e. max_iter on the check grid.)
     const int ncu = h->ncu;

@@ -220,9 +220,11 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma16(SolveArgs a, const unsig
     // ---- per-instance scalars and vectors (rqp_mfma.hip) ----------------------------------------------------------
     for (int i = tid; i < a.nrho && i < 64; i += NT) rhosf[i] = (float)a.rhos[i];
     if (tid < 16) {
-        const int id = blockIdx.x * 16 + tid;
-        const bool ok = id < a.B;
-        const int ri = a.rho_ind[ok ? id : blockIdx.x * 16];
+        const int st = blockIdx.x * 16 + tid;                      // slot -> instance through SolveArgs.order (rqp_mfma.hip)
+        const bool ok = st < a.B;
+        const int s0 = ok ? st : blockIdx.x * 16;
+        const int id = ok ? (a.order ? a.order[st] : st) : a.B;
+        const int ri = a.rho_ind[a.order ? a.order[s0] : s0];
         inst_i[2 * 16 + tid] = id;
         inst_i[3 * 16 + tid] = 0;
         inst_i[4 * 16 + tid] = ri;
@@ -795,8 +797,9 @@ __global__ void __launch_bounds__(256, 1) k_admm_mfma16(SolveArgs a, const unsig
                     }
                     a.rho_ind[bj] = (a.warm_starting || a.keep_state) ? ri : a.rho_ind0;
                     if (refill) {
-                        const int nxt = (int)gridDim.x * 16 + atomicAdd(queue, 1);
-                        if (nxt < a.B) {
+                        const int nsl = (int)gridDim.x * 16 + atomicAdd(queue, 1);
+                        if (nsl < a.B) {
+                            const int nxt = a.order ? a.order[nsl] : nsl;
                             const int rn = a.rho_ind[nxt];
                             inst_i[2 * 16 + j] = nxt;
                             inst_i[3 * 16 + j] = k;
@@ -959,9 +962,15 @@ hipError_t rqp_prepare_mfma16(const rqp_handle* h) {
     if (e == hipSuccess && (h->debug & 2)) e = rqp_raise_lds_limit((const void*)k_admm_mfma16<Cfg16M55, true>, Cfg16M55::lds_bytes());
     return e;
 }
-hipError_t rqp_launch_solve_mfma16(const rqp_handle* h, const SolveArgs& a, hipStream_t s) {
+hipError_t rqp_launch_solve_mfma16(const rqp_handle* h, const SolveArgs& a0, hipStream_t s) {
     const size_t lds = Cfg16M55::lds_bytes();
     const int tiles = (h->B + 15) / 16;
+    SolveArgs a = a0;
+    if (tiles > 1 && h->order_d && a.cont == 0) {    // slots grouped by the rho index the instances start at (rqp_mfma.hip)
+        hipError_t eo = rqp_launch_order_by(h, h->rho_ind, s);
+        if (eo != hipSuccess) return eo;
+        a.order = h->order_d;
+    }
     int grid = tiles;
     int* queue = nullptr;
     if (tiles > h->ncu && h->queue && a.max_iter > 0 && a.check_interval > 0 && a.max_iter % a.check_interval == 0) {

@@ -787,9 +787,50 @@ __global__ void __launch_bounds__(1024) k_order_lpt(int B, const int32_t* __rest
     for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[NBK - 1 - min(max(last_iter[i], 0), NBK - 1)], 1)] = i;
 }
 
-// the same counting sort on another key (the streamed-operand MFMA kernels group their slots by rho index)
+// order[] = instances grouped by key (descending), STABLE: ties keep their index order, so the result is a pure function of the keys
+// (the MFMA kernels group their slots by rho index; which instances share a tile decides when a tile hands its stragglers over, so an
+// arrival-order sort would make those solves irreproducible).  Keys 0 .. 63; one workgroup; one block scan per DISTINCT key.
+__global__ void __launch_bounds__(1024) k_order_stable(int B, const int32_t* __restrict__ key, int32_t* __restrict__ order) {
+    __shared__ unsigned long long present;
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int C = (B + 1023) / 1024, lo = t * C, hi = min(B, lo + C);
+    if (t == 0) present = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (int i = lo; i < hi; ++i) mine |= 1ull << min(max(key[i], 0), 63);
+    for (int off = 32; off >= 1; off >>= 1) mine |= __shfl_xor(mine, off, 64);
+    if (lane == 0 && mine) atomicOr(&present, mine);
+    __syncthreads();
+    unsigned long long pm = present;
+    int b0 = 0;
+    while (pm) {
+        const int k = 63 - __clzll((long long)pm);
+        pm &= ~(1ull << k);
+        int c = 0;
+        for (int i = lo; i < hi; ++i) c += (min(max(key[i], 0), 63) == k);
+        int incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+        }
+        int pos = b0 + woff + incl - c;
+        for (int i = lo; i < hi; ++i)
+            if (min(max(key[i], 0), 63) == k) order[pos++] = i;
+        b0 += tot;
+        __syncthreads();
+    }
+}
+
 hipError_t rqp_launch_order_by(const rqp_handle* h, const int32_t* key, hipStream_t s) {
-    k_order_lpt<<<1, 1024, 0, s>>>(h->B, key, h->order_d);
+    k_order_stable<<<1, 1024, 0, s>>>(h->B, key, h->order_d);
     return hipGetLastError();
 }
 
