@@ -423,7 +423,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
         HIP_TRY(h, hipMalloc((void**)&h->fscratch, h->fscratch_elems * sizeof(double)));
     }
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
-    if (h->use_mfma && h->B > 16)                  // slot order of the MFMA kernels (instances grouped by starting rho index)
+    if ((h->mfmal || h->mfmad) && h->B > 16)       // slot order of the streamed-operand MFMA kernels (grouped by starting rho index)
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
     if (!h->use_mfma && h->B >= (h->resident64 ? 2 : 4) * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));

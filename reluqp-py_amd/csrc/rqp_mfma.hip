@@ -920,12 +920,9 @@ hipError_t rqp_launch_solve_mfma(const rqp_handle* h, const SolveArgs& a0, hipSt
     const size_t lds = CfgM55::lds_floats() * sizeof(float);
     hipError_t e;
     const int tiles = (h->B + 15) / 16;
-    SolveArgs a = a0;
-    if (tiles > 1 && h->order_d && a.cont == 0) {    // slots grouped by the rho index the instances start at (one K pass per distinct index)
-        e = rqp_launch_order_by(h, h->rho_ind, s);
-        if (e != hipSuccess) return e;
-        a.order = h->order_d;
-    }
+    // (slots could be grouped by starting rho index through SolveArgs.order as in rqp_mfmal.hip -- the kernel follows it -- but with
+    //  K in registers a pass per distinct index is cheap here: the closed loop measured 1.4 % SLOWER with the extra sort launch)
+    const SolveArgs& a = a0;
     // More tiles than CUs (one workgroup per CU: 150 KB of LDS, up to 512 registers per lane): persistent grid, slots
     // refill from a queue.  (The refill needs every exit to fall on a check, i.e. max_iter on the check grid.)
     const int ncu = h->ncu;

@@ -965,12 +965,9 @@ hipError_t rqp_prepare_mfma16(const rqp_handle* h) {
 hipError_t rqp_launch_solve_mfma16(const rqp_handle* h, const SolveArgs& a0, hipStream_t s) {
     const size_t lds = Cfg16M55::lds_bytes();
     const int tiles = (h->B + 15) / 16;
-    SolveArgs a = a0;
-    if (tiles > 1 && h->order_d && a.cont == 0) {    // slots grouped by the rho index the instances start at (rqp_mfma.hip)
-        hipError_t eo = rqp_launch_order_by(h, h->rho_ind, s);
-        if (eo != hipSuccess) return eo;
-        a.order = h->order_d;
-    }
+    // (slots could be grouped by starting rho index through SolveArgs.order as in rqp_mfmal.hip -- the kernel follows it -- but with
+    //  K in registers a pass per distinct index is cheap here: the closed loop measured 1.4 % SLOWER with the extra sort launch)
+    const SolveArgs& a = a0;
     int grid = tiles;
     int* queue = nullptr;
     if (tiles > h->ncu && h->queue && a.max_iter > 0 && a.check_interval > 0 && a.max_iter % a.check_interval == 0) {
