@@ -74,7 +74,8 @@ def test_float64_kernels_match_oracle_exactly(n, n_eq, n_ineq, B, seed0, st):
 
 def _shared_cases():
     rs = np.random.RandomState(777)
-    shapes = [(3, 1, 4), (16, 4, 30), (17, 0, 33), (31, 8, 100), (48, 12, 129), (63, 0, 200), (79, 10, 310), (80, 20, 300)]
+    shapes = [(3, 1, 4), (16, 4, 30), (17, 0, 33), (31, 8, 100), (48, 12, 129), (63, 0, 200), (79, 10, 310), (80, 20, 300),
+              (100, 20, 250), (130, 0, 320), (160, 40, 280), (200, 30, 500), (320, 0, 600)]     # beyond the register-resident MFMA tile
     out = []
     for (n, n_eq, n_ineq) in shapes:
         B = int(rs.choice([5, 16, 17, 33]))
@@ -102,10 +103,20 @@ def test_shared_matrix_batches_all_kernels_vs_oracle(n, n_eq, n_ineq, B, seed0, 
     assert list(r.info.status) == list(ref["status"]), m64.kernel
     assert np.array_equal(r.info.iter.cpu().numpy(), ref["iter"]), (m64.kernel, r.info.iter.cpu().numpy(), ref["iter"])
     np.testing.assert_allclose(r.x.cpu().numpy(), ref["x"], rtol=0, atol=1e-8 * scale)
+    if n <= 160 and n_eq + n_ineq <= 320:                             # the float64 MFMA kernel (streamed operands), on request
+        md = reluqpth.ReLU_QP()
+        md.setup(H, g, A, l, u, device=DEV, precision=torch.float64, kernel="mfma", **st)
+        r = md.solve()
+        assert md.kernel == "mfmad" and list(r.info.status) == list(ref["status"])
+        assert np.array_equal(r.info.iter.cpu().numpy(), ref["iter"]), (r.info.iter.cpu().numpy(), ref["iter"])
+        np.testing.assert_allclose(r.x.cpu().numpy(), ref["x"], rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(r.z.cpu().numpy(), ref["z"], rtol=0, atol=1e-8 * scale)
     for kernel in ("mfma", "resident", "wave", "generic"):
         if kernel == "wave" and not _fits("wave", n, n_eq + n_ineq):
             continue
-        if kernel == "mfma" and not (n <= 80 and n_eq + n_ineq <= 320):
+        if kernel == "mfma" and not (n <= 320 and n_eq + n_ineq <= 640):     # (n <= 80, m <= 320: operands in registers; else streamed)
+            continue
+        if kernel == "resident" and not (n <= 104 and n_eq + n_ineq <= 320):
             continue
         m = reluqpth.ReLU_QP()
         m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, kernel=kernel, **st)
