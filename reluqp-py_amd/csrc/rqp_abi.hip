@@ -93,7 +93,7 @@ void free_ws(rqp_handle* h) {
                      (void**)&h->x, (void**)&h->z, (void**)&h->lam, (void**)&h->rho_ind, (void**)&h->rhos_d,
                      (void**)&h->fscratch, (void**)&h->Apack, (void**)&h->Kpack, (void**)&h->Hpack, (void**)&h->Kscale, (void**)&h->W1img, (void**)&h->queue,
                      (void**)&h->flag_d, (void**)&h->order_d, (void**)&h->last_iter_d, (void**)&h->cont_iter_d, (void**)&h->cont_rho_d,
-                     (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc, (void**)&h->wbase_d, (void**)&h->ax_d, (void**)&h->cstat_d,
+                     (void**)&h->Dsc, (void**)&h->Esc, (void**)&h->csc, (void**)&h->wbase_d, (void**)&h->ax_d, (void**)&h->cstat_d, (void**)&h->key_d,
                      (void**)&h->ncont_d};
     // hipFree is one of the calls that invalidate a stream capture in progress (global / thread-local capture modes).  A handle
     // may be destroyed while this thread captures something else (a Python finaliser, an explicit `del`): free under the
@@ -425,6 +425,11 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, hipMalloc((void**)&h->flag_d, sizeof(int32_t)));
     if ((h->mfmal || h->mfmad) && h->B > 16)       // slot order of the streamed-operand MFMA kernels (grouped by starting rho index)
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
+    if (h->mfmal && h->B > 16) {                   // regrouped cold solve (rqp_mfmal.hip): exact state of the instances between its two launches
+        HIP_TRY(h, hipMalloc((void**)&h->ax_d, B * m * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->cont_rho_d, B * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void**)&h->key_d, B * sizeof(int32_t)));
+    }
     if (!h->use_mfma && h->B >= (h->resident64 ? 2 : 4) * h->ncu) {      // dispatch order (see rqp_common.h): batches that outlast one wave of workgroups
         HIP_TRY(h, hipMalloc((void**)&h->order_d, (size_t)h->B * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void**)&h->last_iter_d, (size_t)h->B * sizeof(int32_t)));

@@ -79,6 +79,7 @@ struct rqp_handle {
     int32_t* cont_iter_d = nullptr;   // straggler hand-off MFMA -> resident (SolveArgs)
     double* cont_rho_d = nullptr;
     int handoff_cols = 0;
+    int32_t* key_d = nullptr;     // [B] sort keys of the regrouped cold solve (rqp_mfmal.hip)
     int32_t* order_d = nullptr;   // [B] instance of workgroup i
     int32_t* last_iter_d = nullptr;
     bool order_valid = false;
@@ -119,6 +120,7 @@ struct SolveArgs {
     // its slowest member; once at most `handoff_cols` of its columns are still unsolved at a check, the tile stops and those
     // instances finish on the per-instance resident kernel (`cont` = 1), whose iteration is ~3x shorter than a tile's.
     int handoff_cols;         // MFMA kernel: 0 = off
+    int leave_at, k0;         // k_admm_mfmal, regrouped cold solve: leave behind the check of iteration leave_at (0: off) / cont = 3: resume at k0
     int cont;                 // per-instance kernels: 1 = only instances with status RQP_STATUS_CONTINUE (MFMA hand-off), resumed at
                               // cont_iter with A x recomputed; 2 = only instances with cstat = 1 (they left their rho window),
                               // resumed exactly: cont_iter >= 0: behind the check of that iteration with A x = ax; < 0: from the

@@ -131,10 +131,19 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
         const int s0 = ok ? st : blockIdx.x * 16;                  // padding columns mirror the tile's first instance
         const int idt = a.order ? a.order[s0] : s0;
         const int ri = a.rho_ind[idt];
+        // cont = 3 (second launch of a regrouped cold solve, below): only the instances that left at the first check take part
+        const bool take = ok && (a.cont != 3 || a.info.status[idt] == RQP_STATUS_CONTINUE);
         inst_i[2 * 16 + tid] = idt;
         inst_i[4 * 16 + tid] = ri;
-        inst_i[5 * 16 + tid] = ok ? 0 : 1;                         // padding columns start "done"
-        inst[0 * 16 + tid] = (float)a.rhos[ri];                    // rho_est = rhos[rho_ind]  (:211)
+        inst_i[5 * 16 + tid] = take ? 0 : 1;                       // padding columns (and instances already out) start "done"
+        inst[0 * 16 + tid] = (a.cont == 3 && take) ? (float)a.cont_rho[idt] : (float)a.rhos[ri];   // rho_est = rhos[rho_ind] (:211) / carried
+    }
+    if (a.cont == 3) {                                             // a tile without a continuing instance has nothing to do
+        __syncthreads();
+        int nd0 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nd0 += inst_i[5 * 16 + j];
+        if (nd0 == 16) return;
     }
     // ---- state.  Rows: m tiles T = wave + NW tl, rows 16 T + 4 kq + r of instance i16.  Columns: n tiles t = wave + NW e.
     float zh[TM][4], zl[TM][4], zz[TM][4], lm[TM][4], lb[TM][4], ub[TM][4];
@@ -149,6 +158,11 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
             const size_t o = (size_t)(real ? id : 0) * m + (row < m ? row : 0);
             zh[tl][r] = 0.f;
             zl[tl][r] = 0.f;
+            if (a.cont == 3 && ok) {                             // exact continuation: the float-float A x it left with
+                const double ax = a.ax[o];
+                zh[tl][r] = (float)ax;
+                zl[tl][r] = (float)(ax - (double)zh[tl][r]);
+            }
             zz[tl][r] = ok ? (float)a.z[o] : 0.f;
             lm[tl][r] = ok ? (float)a.lam[o] : 0.f;
             lb[tl][r] = ok ? ((const float*)a.l)[o] : 0.f;
@@ -169,7 +183,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
         }
         if (t < NB) {
             const f32x4 xv = {xs[e][0], xs[e][1], xs[e][2], xs[e][3]};
-            V3[t * 64 + lane] = xv;                                  // start pass: GEMM3 on x
+            V3[t * 64 + lane] = a.cont == 3 ? (f32x4){0.f, 0.f, 0.f, 0.f} : xv;   // start pass: GEMM3 on x (a continuation brings A x along: + 0)
             V1[(MB + t) * 64 + lane] = xv;
         }
     }
@@ -316,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
     };
 
     // phases as in rqp_mfma.hip: 0 start (GEMM3 on x -> A x), 1 iterate, 2 check part 1 (A' lam), 3 check part 2 (H x, decisions)
-    int ph = 0, k = 0, to_chk = a.check_interval;
+    int ph = 0, k = (a.cont == 3) ? a.k0 : 0, to_chk = a.check_interval;   // (k0: a multiple of check_interval)
     bool final_chk = false;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 
@@ -568,7 +582,14 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                     const float td = er > 0.f ? thr_d + er * nanmaxl(nanmaxl(q4, q5), q6) : thr_d;
                     const bool conv = !final_chk && (q0 < tp && q3 < td);                 // :233
                     const bool last = final_chk || k >= kmax;                             // :243 max-iter fallthrough
-                    if (conv || last) {
+                    if (!conv && !last && a.leave_at > 0 && k == a.leave_at) {
+                        // regrouped cold solve: leave behind the FIRST check with the exact state; the second launch continues the
+                        // instance in a tile of instances at the same rho index (rqp_launch_solve_mfmal)
+                        inst_i[5 * 16 + j] = 3;
+                        a.info.status[idj] = RQP_STATUS_CONTINUE;
+                        a.cont_rho[idj] = (double)est;
+                        a.rho_ind[idj] = ri;
+                    } else if (conv || last) {
                         float est_out = est;
                         if (!conv && !final_chk) {                   // max_iter on the check grid: the reference's extra compute_residuals (:243)
                             est_out = est * sqrtf(num / den);
@@ -597,8 +618,9 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                 }
             }
             __syncthreads();
-            if (inst_i[5 * 16 + i16] == 2) {             // this lane's instance just finished: x, z, lam out + the persistent state (:278-305)
-                const bool ws = (a.warm_starting || a.keep_state) != 0;
+            if (inst_i[5 * 16 + i16] >= 2) {             // this lane's instance just finished: x, z, lam out + the persistent state (:278-305)
+                const bool leaves = inst_i[5 * 16 + i16] == 3;               // (3: it continues in the second launch -- state kept, A x too)
+                const bool ws = (a.warm_starting || a.keep_state) != 0 || leaves;
                 int kq_o = kq, id_o = id;
                 asm volatile("" : "+v"(kq_o), "+v"(id_o));
 #pragma unroll
@@ -623,11 +645,12 @@ __global__ void __launch_bounds__(512, 2) k_admm_mfmal(SolveArgs a, const float*
                             if (a.out_lam) ((float*)a.out_lam)[o] = lm[tl][r];
                             a.z[o] = ws ? (double)zz[tl][r] : 0.0;
                             a.lam[o] = ws ? (double)lm[tl][r] : 0.0;
+                            if (leaves) a.ax[o] = (double)zh[tl][r] + (double)zl[tl][r];
                         }
                     }
             }
             __syncthreads();
-            if (tid < 16 && inst_i[5 * 16 + tid] == 2) inst_i[5 * 16 + tid] = 1;
+            if (tid < 16 && inst_i[5 * 16 + tid] >= 2) inst_i[5 * 16 + tid] = 1;
             __syncthreads();
             ri_l = inst_i[4 * 16 + i16];
             set_rho();
@@ -799,13 +822,45 @@ hipError_t rqp_prepare_mfmal(const rqp_handle* h) {
     }
     return e;
 }
+// Regrouped cold solve.  Every distinct rho index among a tile's live columns costs one pass over the dense K stream (the dominant
+// GEMM): a cold batch starts at ONE index, but at the first check its instances split (79 % / 21 % on the sparse config-3 batch) and
+// the tiles run 1.335 passes per iteration from then on.  So a cold solve (warm_starting = 0: the state is cleared anyway) runs as TWO
+// launches: every instance leaves behind its first check with its exact state (x, z, lam, float-float A x, carried rho estimate: the
+// continuation is bit-identical to an uninterrupted solve), the slots are re-sorted by the NEW indices (stable counting sort; the
+// instances that converged at the first check go last), and the second launch continues in homogeneous tiles.  No host round trip.
+__global__ void k_regroup_key(int B, const int32_t* __restrict__ status, const int32_t* __restrict__ rho_ind, int32_t* __restrict__ key) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) key[i] = status[i] == RQP_STATUS_CONTINUE ? rho_ind[i] + 1 : 0;
+}
+
 hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a0, hipStream_t s) {
     const int grid = (h->B + 15) / 16;
     SolveArgs a = a0;
-    if (grid > 1 && h->order_d) {                // slots grouped by the rho index the instances start at (k_order_lpt: a counting sort)
+    if (grid > 1 && h->order_d) {                // slots grouped by the rho index the instances start at (k_order_stable)
         hipError_t e = rqp_launch_order_by(h, h->rho_ind, s);
         if (e != hipSuccess) return e;
         a.order = h->order_d;
+    }
+    const bool two = grid > 1 && h->order_d && h->ax_d && h->cont_rho_d && h->key_d && !a.warm_starting && !a.keep_state && a.cont == 0 &&
+                     a.info.status && a.check_interval > 0 && a.max_iter > a.check_interval && h->nrho <= 62 && !(h->debug & 2);
+    if (two) {
+        const size_t lds = ml_lds_floats() * sizeof(float);
+        SolveArgs p1 = a;
+        p1.leave_at = a.check_interval;
+        p1.ax = h->ax_d;
+        p1.cont_rho = h->cont_rho_d;
+        k_admm_mfmal<false><<<grid, ML_NT, lds, s>>>(p1, h->W1img, nullptr);
+        k_regroup_key<<<(h->B + 255) / 256, 256, 0, s>>>(h->B, a.info.status, h->rho_ind, h->key_d);
+        hipError_t e = rqp_launch_order_by(h, h->key_d, s);
+        if (e != hipSuccess) return e;
+        SolveArgs p2 = a;
+        p2.cont = 3;
+        p2.k0 = a.check_interval;
+        p2.ax = h->ax_d;
+        p2.cont_rho = h->cont_rho_d;
+        p2.order = h->order_d;
+        k_admm_mfmal<false><<<grid, ML_NT, lds, s>>>(p2, h->W1img, nullptr);
+        return hipGetLastError();
     }
     if (h->debug & 2) {          // diagnostic build: per-segment tick shares of the iteration (synchronous, debug only)
         unsigned long long* dbg = nullptr;

@@ -82,6 +82,34 @@ def test_sparse_c3_full_shape_vs_streaming_kernel_oracle_and_kkt():
     assert eq.sum() == 240 and float((ra.z.cpu().double().numpy()[:, eq] - l[:, eq]).__abs__().max()) < 1e-6
 
 
+def test_regrouped_cold_solve_is_bit_identical_to_the_single_launch():
+    """warm_starting=False: a cold solve runs as two launches -- every instance leaves behind its first check with its exact state
+    (x, z, lam, float-float A x, carried rho estimate), the slots are re-sorted by the new rho indices, the second launch continues in
+    homogeneous tiles (one pass of the dense K stream per distinct index of a tile).  The first solve of a warm_starting=True handle
+    runs the same problems in ONE launch: every output must agree bit for bit, including the check trace and max_iter exits."""
+    B = 1000
+    ctl, H, g, A, l, u = _c3_sparse(B, seed=17)
+    g = g + np.random.RandomState(3).randn(B, 320) * np.linspace(0.0, 2.0, B)[:, None]       # (spread the rho paths)
+    for kw in (dict(eps_abs=1e-3), dict(eps_abs=1e-6, max_iter=150), dict(eps_abs=1e-4, check_interval=10, eps_rel=1e-4)):
+        outs = []
+        for ws in (False, True):
+            m = reluqpth.ReLU_QP()
+            m.collect_trace = True
+            m.prefill_outputs = True
+            m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, kernel="mfma", warm_starting=ws, **kw)
+            assert m.kernel == "mfmal"
+            r = m.solve()
+            outs.append((r.x.clone(), r.z.clone(), r.y.clone(), r.info.iter.clone(), r.info.status_code.clone(), r.info.rho_ind.clone(),
+                         r.info.pri_res.clone(), r.info.dua_res.clone(), r.info.rho_estimate.clone(), r.info.obj_val.clone(),
+                         torch.nan_to_num(m.last_trace.clone(), nan=-1.0)))
+            if not ws:                                                # cold semantics: the state is cleared, the index reset
+                xs, ri = m.get_state()
+                assert float(xs.abs().max()) == 0.0 and bool((ri == m._rho_ind0()).all())
+        for k, (ta, tb) in enumerate(zip(*outs)):
+            assert torch.equal(ta, tb), (kw, k)
+        assert len(torch.unique(outs[0][5])) >= 2 and not bool((outs[0][3] == -7).any())
+
+
 def test_more_tiles_than_cus():
     """Three rounds of 16-instance tiles per CU and a ragged tail: every instance must come out as from the streaming kernel --
     same iteration counts, same solution; a warm re-solve; max_iter on and off the check grid at this grid size.  (A persistent
