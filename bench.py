@@ -56,8 +56,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA pea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)     # (one per fresh batch: every handle has solved once before the timed steps)
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak) / in total (strong); default 4096 "
                                                              "(c4: 8192 weak, 65536 strong)")
     ap.add_argument("--n", type=int, default=100)
