@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QP solves/sec of the MI355X ReLU-QP hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 4
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
