@@ -482,6 +482,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     }
     if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_scale_vecs(h, h->g, h->l, h->u, s));    // g <- c D g, l/u <- E l/u
     h->is_setup = true;
+    h->cold_state = true;
     rc = rqp_clear_primal_dual(h, stream);      // zero state, rho_ind0 (reluqpth.py:148-153)
     if (h->debug & 1) {                         // host-side split of a setup call (synchronous, debug only)
         const auto t_enq = std::chrono::steady_clock::now();
@@ -571,6 +572,7 @@ int rqp_warm_start(rqp_handle* h, const void* x, const void* z, const void* lam,
     HIP_TRY(h, hipSetDevice(h->device));
     const int ri = has_rho ? argmin_abs(h->rhos, rho) : 0;          // reluqpth.py:273-274
     HIP_TRY(h, rqp_launch_state_set(h, x, z, lam, has_rho, ri, (hipStream_t)stream));
+    if (x || z || lam) h->cold_state = false;   // (a rho alone moves every instance to one index: still the common state)
     if (h->st.scaling > 0 && (x || z || lam))      // caller space -> scaled space
         HIP_TRY(h, rqp_launch_scale_state(h, x ? h->x : nullptr, z ? h->z : nullptr, lam ? h->lam : nullptr, (hipStream_t)stream));
     return RQP_OK;
@@ -585,6 +587,7 @@ int rqp_clear_primal_dual(rqp_handle* h, void* stream) {
     HIP_TRY(h, hipMemsetAsync(h->z, 0, (size_t)h->B * h->m * sizeof(double), s));
     HIP_TRY(h, hipMemsetAsync(h->lam, 0, (size_t)h->B * h->m * sizeof(double), s));
     HIP_TRY(h, rqp_launch_state_set(h, nullptr, nullptr, nullptr, 1, h->rho_ind0, s));
+    h->cold_state = true;
     return RQP_OK;
 }
 
@@ -606,6 +609,8 @@ int rqp_solve(rqp_handle* h, void* x, void* z, void* lam, const rqp_info* info, 
     hipStream_t s = (hipStream_t)stream;
     SolveArgs a = make_solve_args(h);
     a.mode = 0;
+    a.cold = h->cold_state ? 1 : 0;
+    h->cold_state = !h->st.warm_starting;          // (a cold-start handle clears its state in the kernel)
     a.out_x = x; a.out_z = z; a.out_lam = lam;
     if (info) a.info = *info;
     if (a.info.trace && a.info.trace_cap < 1) return fail_arg(h, "rqp_solve: trace without capacity");
@@ -687,6 +692,7 @@ int rqp_iterate(rqp_handle* h, int32_t k, void* stream) {
     SolveArgs a = make_solve_args(h);
     a.mode = 1;
     a.max_iter = k;
+    h->cold_state = false;
     if (h->windowed) {                              // (test hook: no exit-and-continue here -- every window is centred first)
         const int rc = refactor_windows(h, 1, (hipStream_t)stream);
         if (rc != RQP_OK) return rc;

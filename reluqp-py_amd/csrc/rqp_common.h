@@ -35,6 +35,8 @@ struct rqp_handle {
     int n = 0, m = 0, B = 0, ldn = 0, ldm = 0, nrho = 0, rho_ind0 = 0, nmat = 0;
     size_t esz = 4;
     bool is_setup = false;
+    bool cold_state = false;      // every instance sits at the zero state and ONE rho index (after setup / clear_primal_dual, or a solve
+                                  // with warm_starting = 0): k_admm_mfmal then regroups the solve at its first check
     std::vector<double> rhos;
 
     void *Ht = nullptr, *A = nullptr, *At = nullptr, *K = nullptr;
@@ -120,6 +122,7 @@ struct SolveArgs {
     // its slowest member; once at most `handoff_cols` of its columns are still unsolved at a check, the tile stops and those
     // instances finish on the per-instance resident kernel (`cont` = 1), whose iteration is ~3x shorter than a tile's.
     int handoff_cols;         // MFMA kernel: 0 = off
+    int cold;                 // the batch starts from the common cold state (rqp_handle.cold_state)
     int leave_at, k0;         // k_admm_mfmal, regrouped cold solve: leave behind the check of iteration leave_at (0: off) / cont = 3: resume at k0
     int cont;                 // per-instance kernels: 1 = only instances with status RQP_STATUS_CONTINUE (MFMA hand-off), resumed at
                               // cont_iter with A x recomputed; 2 = only instances with cstat = 1 (they left their rho window),

@@ -824,7 +824,7 @@ hipError_t rqp_prepare_mfmal(const rqp_handle* h) {
 }
 // Regrouped cold solve.  Every distinct rho index among a tile's live columns costs one pass over the dense K stream (the dominant
 // GEMM): a cold batch starts at ONE index, but at the first check its instances split (79 % / 21 % on the sparse config-3 batch) and
-// the tiles run 1.335 passes per iteration from then on.  So a cold solve (warm_starting = 0: the state is cleared anyway) runs as TWO
+// the tiles run 1.335 passes per iteration from then on.  So a cold solve (warm_starting = 0, or the first solve of a handle) runs as TWO
 // launches: every instance leaves behind its first check with its exact state (x, z, lam, float-float A x, carried rho estimate: the
 // continuation is bit-identical to an uninterrupted solve), the slots are re-sorted by the NEW indices (stable counting sort; the
 // instances that converged at the first check go last), and the second launch continues in homogeneous tiles.  No host round trip.
@@ -841,7 +841,7 @@ hipError_t rqp_launch_solve_mfmal(const rqp_handle* h, const SolveArgs& a0, hipS
         if (e != hipSuccess) return e;
         a.order = h->order_d;
     }
-    const bool two = grid > 1 && h->order_d && h->ax_d && h->cont_rho_d && h->key_d && !a.warm_starting && !a.keep_state && a.cont == 0 &&
+    const bool two = grid > 1 && h->order_d && h->ax_d && h->cont_rho_d && h->key_d && (!a.warm_starting || a.cold) && !a.keep_state && a.cont == 0 &&
                      a.info.status && a.check_interval > 0 && a.max_iter > a.check_interval && h->nrho <= 62 && !(h->debug & 2);
     if (two) {
         const size_t lds = ml_lds_floats() * sizeof(float);

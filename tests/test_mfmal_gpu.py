@@ -85,7 +85,7 @@ def test_sparse_c3_full_shape_vs_streaming_kernel_oracle_and_kkt():
 def test_regrouped_cold_solve_is_bit_identical_to_the_single_launch():
     """warm_starting=False: a cold solve runs as two launches -- every instance leaves behind its first check with its exact state
     (x, z, lam, float-float A x, carried rho estimate), the slots are re-sorted by the new rho indices, the second launch continues in
-    homogeneous tiles (one pass of the dense K stream per distinct index of a tile).  The first solve of a warm_starting=True handle
+    homogeneous tiles (one pass of the dense K stream per distinct index of a tile).  A handle whose state came from the caller
     runs the same problems in ONE launch: every output must agree bit for bit, including the check trace and max_iter exits."""
     B = 1000
     ctl, H, g, A, l, u = _c3_sparse(B, seed=17)
@@ -98,6 +98,8 @@ def test_regrouped_cold_solve_is_bit_identical_to_the_single_launch():
             m.prefill_outputs = True
             m.setup(H, g, A, l, u, device=DEV, precision=torch.float32, kernel="mfma", warm_starting=ws, **kw)
             assert m.kernel == "mfmal"
+            if ws:                     # a caller-provided state (here: the same zeros) is not known to be the common cold state:
+                m.warm_start(x=np.zeros((B, 320)))        # this handle solves in ONE launch
             r = m.solve()
             outs.append((r.x.clone(), r.z.clone(), r.y.clone(), r.info.iter.clone(), r.info.status_code.clone(), r.info.rho_ind.clone(),
                          r.info.pri_res.clone(), r.info.dua_res.clone(), r.info.rho_estimate.clone(), r.info.obj_val.clone(),
