@@ -221,6 +221,8 @@ def pmc_traffic(kernel, args, kern_s):
         with open(path) as f:
             pm = json.load(f)
         nbytes = (2.0 * float(pm["FETCH_SIZE"]) + float(pm["WRITE_SIZE"])) * 1024.0
+        if kernel == "mfmal":          # a cold solve of this kernel is two launches (regrouped at the first check): pmc.json is per launch
+            nbytes *= 2.0
     except (OSError, KeyError, ValueError):
         return None, None
     return nbytes / kern_s / 1e9, "profiles/" + name + " (bytes per launch / this run's kernel time)"
