@@ -8,7 +8,8 @@ import reluqp.reluqpth as reluqpth
 from reluqp import mpc
 dev = torch.device("cuda:0")
 Ad, Bd = mpc.random_plant(12, 4, seed=0)
-ctl = mpc.LinearMPC(Ad, Bd, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form="sparse")
+form = sys.argv[1] if len(sys.argv) > 1 else "sparse"
+ctl = mpc.LinearMPC(Ad, Bd, np.eye(12), 0.1 * np.eye(4), 20, 0.5, 10.0, form=form)
 B = 4096
 x0 = np.random.RandomState(1).randn(B, 12)
 g, l, u = ctl.qp_vectors(x0)
