@@ -108,6 +108,7 @@ void free_ws(rqp_handle* h) {
     if (swapped) (void)hipThreadExchangeStreamCaptureMode(&cmode);
     h->ncont_h = nullptr;
     h->windowed = false;
+    h->borrow_A = false;
     h->is_setup = false;
     h->order_valid = false;
     h->resident = false;
@@ -175,7 +176,7 @@ SetupArgs make_setup_args(const rqp_handle* h, const void* H, const void* g, con
     a.sigma = h->st.sigma;
     a.eq_tol = h->st.eq_tol;
     a.H_in = H; a.A_in = A; a.g_in = g; a.l_in = l; a.u_in = u;
-    a.Ht = h->Ht; a.A = h->A; a.At = h->At; a.K = h->K; a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
+    a.Ht = h->Ht; a.A = h->borrow_A ? const_cast<void*>(A) : h->A; a.At = h->At; a.K = h->K; a.g = h->g; a.l = h->l; a.u = h->u; a.c = h->c;
     a.G = h->G;
     a.rhos = h->rhos_d;
     a.fscratch = h->fscratch;
@@ -264,6 +265,7 @@ int select_kernels(rqp_handle* h) {
     h->windowed = !h->dims.shared_mats && h->nmat >= 32 && h->nrho > RQP_WINDOW && !(h->dims.flags & RQP_FLAG_FULL_LADDER) &&
                   !h->st.check_infeasibility && !h->use_mfma;
     if (h->windowed) h->kwin = RQP_WINDOW;
+    h->borrow_A = h->windowed && h->resident && h->st.scaling <= 0 && h->ldn == h->n;     // (rqp_common.h)
     if (h->use_mfma) h->kernel_name = h->mfmad ? "mfmad" : (h->mfmal ? "mfmal" : (h->mfma16 ? "mfma16" : "mfma"));
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
@@ -276,7 +278,7 @@ int select_kernels(rqp_handle* h) {
 int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     HIP_TRY(h, rqp_launch_pack_mats(h, a, s));
     if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_ruiz(h, s));       // Ht, A, At scaled in place; D, E, c kept for the boundary
-    HIP_TRY(h, rqp_launch_gram(h, a, s));
+    if (a.A) HIP_TRY(h, rqp_launch_gram(h, a, s));                  // (NULL: a handle without a copy of A that keeps its A -- G = A'cA stands)
     HIP_TRY(h, rqp_launch_factor(h, a, s));
     if (h->resident) {
         if (!h->Apack) {
@@ -288,7 +290,7 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
             if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
             HIP_TRY(h, rqp_prepare_res2(h));
         }
-        HIP_TRY(h, rqp_launch_pack_res2(h, nullptr, s));
+        HIP_TRY(h, rqp_launch_pack_res2(h, a.A, nullptr, s));
     }
     if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
@@ -397,7 +399,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     }
     const size_t n = h->n, m = h->m, B = h->B, nm = h->nmat, e = h->esz;
     HIP_TRY(h, hipMalloc(&h->Ht, nm * n * h->ldn * e));
-    HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));
+    if (!h->borrow_A) HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));     // (rqp_common.h: borrow_A)
     // A' (the streaming kernel's A dx operand and the wavefront kernel's column role): not on a windowed resident handle, whose
     // solve / iterate / residuals all run on k_admm_res2 and which refuses the certificate pass (0.5 GB and 0.4 ms at B = 4096)
     if (!(h->windowed && h->resident)) HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
@@ -598,7 +600,7 @@ static int refactor_windows(rqp_handle* h, int all, hipStream_t s) {
     SetupArgs f = make_setup_args(h, nullptr, nullptr, nullptr, nullptr, nullptr);
     f.only = h->cstat_d;
     HIP_TRY(h, rqp_launch_factor(h, f, s));
-    if (h->resident) HIP_TRY(h, rqp_launch_pack_res2(h, h->cstat_d, s));
+    if (h->resident) HIP_TRY(h, rqp_launch_pack_res2(h, nullptr, h->cstat_d, s));
     return RQP_OK;
 }
 

@@ -69,6 +69,11 @@ struct rqp_handle {
     // to a solve on the whole ladder.
     int kwin = 0;                 // slots per matrix (nrho when not windowed)
     bool windowed = false;
+    // Windowed float32 resident handles without Ruiz scaling keep NO row-major copy of A: nothing reads it after setup (solve,
+    // iterate and residuals run on the register image Apack; a window move needs only sym(H) and G), so k_gram2 and k_pack_res2
+    // read the caller's A during rqp_setup / rqp_update_mats (same stream order as every other input) -- 0.5 GB and 0.3 ms of
+    // the headline batch's setup.  Needs the caller's row pitch to be the packed one (n % 4 == 0).
+    bool borrow_A = false;
     int32_t* wbase_d = nullptr;   // [nmat] ladder index of slot 0
     double* ax_d = nullptr;       // [B][m] A x of an instance that left its window (exact continuation)
     int32_t* cstat_d = nullptr;   // [B] 1: left its window, continue after the re-factor
@@ -185,7 +190,7 @@ size_t rqp_generic_lds_bytes(const rqp_handle* h);
 // resident (register/LDS) variant, float32 only
 bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
-hipError_t rqp_launch_pack_res2(const rqp_handle* h, const int32_t* only, hipStream_t s);
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s);   // A_src NULL: Apack is kept
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 
 bool rqp_res64_fits(const rqp_handle* h);

@@ -841,17 +841,19 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, int xoff, const flo
     extern __shared__ __attribute__((aligned(16))) float stage[];
     const int bx = blockIdx.x + xoff;
     if (bx == 0) {
-        for (int i = t; i < m * ldn; i += NT) stage[i] = Am[i];
-        __syncthreads();
-        f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
-        for (int pair = 0; pair < AE2; ++pair) {
-            const int r = RB * pl + 2 * (pair / CQ), c = CW * w + CQ * q + pair % CQ;
-            f2 v;
-            v.x = (r < m && c < n) ? stage[r * ldn + c] : 0.f;
-            v.y = (r + 1 < m && c < n) ? stage[(r + 1) * ldn + c] : 0.f;
-            Ap[(size_t)pair * NT + t] = v;
+        if (A) {                                                   // (NULL: rqp_update_mats with a new H only -- Apack stands)
+            for (int i = t; i < m * ldn; i += NT) stage[i] = Am[i];
+            __syncthreads();
+            f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
+            for (int pair = 0; pair < AE2; ++pair) {
+                const int r = RB * pl + 2 * (pair / CQ), c = CW * w + CQ * q + pair % CQ;
+                f2 v;
+                v.x = (r < m && c < n) ? stage[r * ldn + c] : 0.f;
+                v.y = (r + 1 < m && c < n) ? stage[(r + 1) * ldn + c] : 0.f;
+                Ap[(size_t)pair * NT + t] = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int i = t; i < n * ldn; i += NT) stage[i] = Hm[i];
         __syncthreads();
         float4* Hp = (float4*)(Hpack + (size_t)mat * HU * NT * 4);
@@ -934,32 +936,32 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
 }
 
 template <class C>
-static hipError_t pack_t(const rqp_handle* h, const int32_t* only, hipStream_t s) {
+static hipError_t pack_t(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s) {
     const size_t stage_ah = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
     const size_t stage_k = (size_t)h->n * h->ldn * sizeof(float);
     // only != NULL: the K blocks of the matrices whose window moved (A and H have not changed)
     if (h->dims.tile_dtype == RQP_TILE_F16) {
         if (!only)
-            k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)h->A, (const float*)h->Ht,
+            k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)A_src, (const float*)h->Ht,
                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, nullptr);
-        k_pack_res2<C, true><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)h->A, (const float*)h->Ht,
+        k_pack_res2<C, true><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)nullptr, (const float*)h->Ht,
                                                                           (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, only);
     } else {
         if (!only)
-            k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)h->A, (const float*)h->Ht,
+            k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)A_src, (const float*)h->Ht,
                                                                           (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
         if (!h->k_direct)       // (low-memory handles read K from the row-major table: only the (A, H) images)
-            k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)h->A, (const float*)h->Ht,
+            k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)nullptr, (const float*)h->Ht,
                                                                                (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, only);
     }
     return hipGetLastError();
 }
-hipError_t rqp_launch_pack_res2(const rqp_handle* h, const int32_t* only, hipStream_t s) {
+hipError_t rqp_launch_pack_res2(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s) {
     switch (res2_pick(h)) {
-        case 0: return pack_t<Cfg2C4>(h, only, s);
-        case 1: return pack_t<Cfg2M>(h, only, s);
-        case 3: return pack_t<Cfg2N>(h, only, s);
-        default: return pack_t<Cfg2C2>(h, only, s);
+        case 0: return pack_t<Cfg2C4>(h, A_src, only, s);
+        case 1: return pack_t<Cfg2M>(h, A_src, only, s);
+        case 3: return pack_t<Cfg2N>(h, A_src, only, s);
+        default: return pack_t<Cfg2C2>(h, A_src, only, s);
     }
 }
 

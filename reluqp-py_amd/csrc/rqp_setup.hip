@@ -35,7 +35,7 @@ __global__ void k_pack_mats(SetupArgs a) {
             Ht[i] = (c < a.n) ? T(0.5) * (H[(size_t)c * a.n + r] + H[(size_t)r * a.n + c]) : T(0);
         }
     }
-    if (a.A_in) {
+    if (a.A_in && a.A != a.A_in) {                  // (a.A == a.A_in: the handle keeps no copy of A, rqp_handle.borrow_A)
         const T* A = (const T*)a.A_in + (size_t)mat * a.m * a.n;
         T* Ap = (T*)a.A + (size_t)mat * a.m * a.ldn;
         T* At = (T*)a.At + (size_t)mat * a.n * a.ldm;

@@ -187,6 +187,19 @@ def test_window_warm_start_iterate_and_K_outside(prec, kernel):
     for m_ in (mw, mf):
         m_.update(Hx=H2)
     _same(_snap(mw.solve(), mw), _snap(mf.solve(), mf), "after update(Hx)")
+    # new A alone, then both (a windowed float32 resident handle keeps no row-major copy of A -- rqp_handle.borrow_A: with a new
+    # H only, G = A'cA and the register image of A stand; with a new A both are rebuilt from the caller's matrix)
+    A2 = (A * 1.02).astype(dt)
+    for m_ in (mw, mf):
+        m_.update(Ax=A2)
+    _same(_snap(mw.solve(), mw), _snap(mf.solve(), mf), "after update(Ax)")
+    for m_ in (mw, mf):
+        m_.update(Hx=H, Ax=A)
+        m_.clear_primal_dual()
+    _same(_snap(mw.solve(), mw), _snap(mf.solve(), mf), "after update(Hx, Ax)")
+    for m_ in (mw, mf):
+        m_.update(Hx=H2)
+    _same(_snap(mw.solve(), mw), _snap(mf.solve(), mf), "after a second update(Hx)")
 
 
 def test_window_rules():
