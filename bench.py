@@ -359,9 +359,13 @@ def main():
         hist = (th / args.history_steps, kh / args.history_steps, float(rh.info.iter.to(torch.float64).sum()))
         mdl.dispatch_history(False)
 
-    elapsed, (kern_avg_s, setup_max, rank_iters_max, hist_step, hist_kern, hist_iters), tot_iters, tot_solved, tot_qps = D.reduce_report(
-        dist, dev, elapsed, sum_iters, solved, B,
-        extra_max=[kern_s / max(1, args.steps), setup_s, sum_iters] + (list(hist) if hist else [0.0, 0.0, 0.0]))
+    # (the minima over the ranks ride along as maxima of the negated values: SURVEY.md 8(e) asks for the min / max per-GPU time)
+    elapsed_rank = elapsed
+    elapsed, (kern_avg_s, setup_max, rank_iters_max, hist_step, hist_kern, hist_iters, neg_kern_min, neg_el_min, neg_it_min), \
+        tot_iters, tot_solved, tot_qps = D.reduce_report(
+            dist, dev, elapsed, sum_iters, solved, B,
+            extra_max=[kern_s / max(1, args.steps), setup_s, sum_iters] + (list(hist) if hist else [0.0, 0.0, 0.0]) +
+                      [-kern_s / max(1, args.steps), -elapsed_rank, -sum_iters])
 
     if rank == 0:
         step_s = elapsed / args.steps
@@ -459,6 +463,10 @@ def main():
                                                     (roof["peak"] if roof["unit"] == "TFLOP/s" else float("nan")),
                                    "note": "one batch solved repeatedly, workgroups issued longest-first by the previous solve's "
                                            "iteration counts; NOT the headline"}
+        if world > 1:     # per-GPU spread (instances are independent: a rank's time is its own shard's work, nothing is exchanged)
+            out["per_gpu"] = {"kernel_ms_min": -neg_kern_min * 1e3, "kernel_ms_max": kern_avg_s * 1e3,
+                              "ms_per_step_min": -neg_el_min / args.steps * 1e3, "ms_per_step_max": step_s * 1e3,
+                              "iterations_per_step_min": -neg_it_min, "iterations_per_step_max": rank_iters_max}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]

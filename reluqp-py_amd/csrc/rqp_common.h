@@ -70,7 +70,7 @@ struct rqp_handle {
     int kwin = 0;                 // slots per matrix (nrho when not windowed)
     bool windowed = false;
     // Windowed float32 resident handles without Ruiz scaling keep NO row-major copy of A: nothing reads it after setup (solve,
-    // iterate and residuals run on the register image Apack; a window move needs only sym(H) and G), so k_gram2 and k_pack_res2
+    // iterate and residuals run on the register image Apack; a window move needs only sym(H) and G), so k_gram_mfma and k_pack_res2
     // read the caller's A during rqp_setup / rqp_update_mats (same stream order as every other input) -- 0.5 GB and 0.3 ms of
     // the headline batch's setup.  Needs the caller's row pitch to be the packed one (n % 4 == 0).
     bool borrow_A = false;

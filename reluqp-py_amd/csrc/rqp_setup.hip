@@ -8,6 +8,7 @@
 //
 // Kernels: k_pack (casts/transposes, QP.__init__ classes.py:4-30), k_gram, k_factor,
 // plus the small state/vector movers behind update()/warm_start()/get_state().
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -70,7 +71,11 @@ __global__ void k_pack_vecs(SetupArgs a) {
 }
 
 hipError_t rqp_launch_pack_mats(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
-    dim3 grid(64, h->nmat);
+    // blocks per matrix: ~8 elements per thread of the largest copy (64 blocks of 256 threads on a 32 x 32 / 64 x 32 instance
+    // were 16 384 threads for 2 048 elements: 0.40 ms for the 8 192 instances of the config-4 batch)
+    const size_t big = (size_t)(h->m > h->n ? h->m : h->n) * (h->ldn > h->ldm ? h->ldn : h->ldm);
+    const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (big + 2047) / 2048));
+    dim3 grid(gx, h->nmat);
     if (h->esz == 4)
         k_pack_mats<float><<<grid, 256, 0, s>>>(a);
     else
@@ -223,66 +228,104 @@ __global__ void __launch_bounds__(256) k_gram(SetupArgs a) {
         }
 }
 
-// n <= 16 RT: one workgroup per matrix in the 16 x 16 x (RT x RT) register layout of k_factor_reg2 (upper blocks only,
-// like that kernel -- the lower blocks of G are never written nor read): 2 RT LDS reads for
-// RT^2 FMAs (the 64 x 64-tile kernel above spends 8 reads on 16 FMAs and pads n = 100 to two tiles per dimension).
-template <typename T, int RT>
-__global__ void __launch_bounds__(256, 3) k_gram2(SetupArgs a) {
-    constexpr int NMAX = 16 * RT, KB = 16;
-    __shared__ __attribute__((aligned(16))) double sR[KB][NMAX];         // c_k A[k][:]
-    __shared__ __attribute__((aligned(16))) double sC[KB][NMAX];         // A[k][:]
-    const int mat = blockIdx.x, n = a.n, m = a.m;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const T* A = (const T*)a.A + (size_t)mat * m * a.ldn;
+// n <= 112 (the sizes of k_factor_reg2, which reads the upper 16 x 16 blocks of G only): the product on the float64 matrix pipe.
+// G tile (I, J) = sum_k (c_k A[k][16 I + .])' A[k][16 J + .] is one chain of
+// v_mfma_f64_16x16x4_f64 over the rows of A, four rows per instruction.  Both operands of every tile are the SAME per-lane
+// values -- lane (kq, i16) holds A[k0 + kq][16 T + i16] for the RT column tiles T (A operand: row i16 of the transposed tile,
+// k = kq, times c; B operand: k = kq, column i16) -- so a k-step is RT loads straight from global memory (64-byte row
+// segments, no LDS, no barrier) for up to 7 MFMAs per wave.  The RT (RT + 1) / 2 upper tiles are dealt to the 4 waves (tile g to
+// wave g mod 4: compile-time (I, J) per wave behind a wave-uniform switch, or the operand registers would be indexed dynamically);
+// loads run KU k-steps ahead in a second register set.  D layout (rqp_mfmad.hip): register r of lane (kq, i16) is row kq + 4 r,
+// column i16 of the tile.  (Its predecessor k_gram2 -- 16 x 16 threads x RT x RT register tiles, rows of A staged in LDS, 2 RT LDS
+// reads per RT^2 / 2 float64 FMAs -- took 0.79 ms for the 4096 matrices of the headline batch; this kernel 0.44 ms.)
+typedef double gm_d4 __attribute__((ext_vector_type(4)));
+constexpr int gm_tile_I(int g, int RT) { int I = 0; while (g >= RT - I) { g -= RT - I; ++I; } return I; }
+constexpr int gm_tile_J(int g, int RT) { int I = 0; while (g >= RT - I) { g -= RT - I; ++I; } return I + g; }
+
+template <typename T, int RT, int W>
+__device__ __forceinline__ void gram_mfma_wave(const SetupArgs& a, int mat, int lane) {
+    constexpr int NTILE = RT * (RT + 1) / 2, TPW = (NTILE - W + 3) / 4, KU = 4;
+    const int n = a.n, m = a.m, ldn = a.ldn, i16 = lane & 15, kq = lane >> 4;
+    const T* A = (const T*)a.A + (size_t)mat * m * ldn;
     const T* cv = (const T*)a.c + (size_t)mat * m;                       // shared mats: instance 0's pattern (mat = 0)
-    double acc[RT][RT];                                                  // blocks i <= j only: k_factor_reg2 reads nothing else of G
+    gm_d4 acc[TPW > 0 ? TPW : 1];
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int e = 0; e < TPW; ++e) acc[e] = (gm_d4){0.0, 0.0, 0.0, 0.0};
+    // Branch-free loads: row and column indices are clamped into the matrix.  A row k >= m is switched off through its scale
+    // (c = 0: the A operand of the MFMA is zero); a column >= n only feeds tile rows / columns >= n, which are never stored.
+    // (Guarded loads compiled to one exec-masked branch per load: 1.2 ms for the headline batch against 0.79 ms of the VALU kernel.)
+    int coff[RT];
 #pragma unroll
-        for (int j = i; j < RT; ++j) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < m; k0 += KB) {
-        for (int e = tid; e < KB * NMAX; e += 256) {
-            const int kk = e / NMAX, col = e % NMAX, k = k0 + kk;
-            const double v = (k < m && col < n) ? (double)A[(size_t)k * a.ldn + col] : 0.0;
-            sC[kk][col] = v;
-            sR[kk][col] = (k < m) ? v * (double)cv[k] : 0.0;
+    for (int t = 0; t < RT; ++t) coff[t] = min(16 * t + i16, n - 1);
+    auto load = [&](int k0, T (&v)[KU][RT], T (&c)[KU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = k0 + 4 * u + kq, kc = min(k, m - 1);
+            const T cl = cv[kc];
+            c[u] = (k < m) ? cl : T(0);
+            const T* Ar = A + (size_t)kc * ldn;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) v[u][t] = Ar[coff[t]];
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < KB; ++kk) {
-            double rr[RT], cc[RT];
+    };
+    auto compute = [&](const T (&v)[KU][RT], const T (&c)[KU]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) rr[i] = sR[kk][ty + 16 * i];
+        for (int u = 0; u < KU; ++u) {
+            double vd[RT], vc[RT];
 #pragma unroll
-            for (int j = 0; j < RT; ++j) cc[j] = sC[kk][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = i; j < RT; ++j) acc[i][j] = fma(rr[i], cc[j], acc[i][j]);
+            for (int t = 0; t < RT; ++t) {
+                vd[t] = (double)v[u][t];
+                vc[t] = vd[t] * (double)c[u];
+            }
+            rqp_static_for(std::make_integer_sequence<int, TPW>{}, [&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = decltype(ec)::value, I = gm_tile_I(W + 4 * e, RT), J = gm_tile_J(W + 4 * e, RT);   // (compile time:
+                acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[I], vd[J], acc[e], 0, 0, 0);    //  left to the optimiser, the index loops ran on the SALU)
+            });
         }
-        __syncthreads();
+    };
+    T v0[KU][RT], v1[KU][RT], c0[KU], c1[KU];
+    load(0, v0, c0);
+    for (int k0 = 0; k0 < m; k0 += 8 * KU) {                             // two groups of KU k-steps per trip: explicit ping-pong
+        load(k0 + 4 * KU, v1, c1);                                       // (rows >= m load zeros)
+        compute(v0, c0);
+        load(k0 + 8 * KU, v0, c0);
+        compute(v1, c1);
     }
     double* G = a.G + (size_t)mat * n * n;
+    rqp_static_for(std::make_integer_sequence<int, TPW>{}, [&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value, I = gm_tile_I(W + 4 * e, RT), J = gm_tile_J(W + 4 * e, RT);
+        const int c = 16 * J + i16;
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = i; j < RT; ++j) {
-            const int r = ty + 16 * i, c = tx + 16 * j;
-            if (r < n && c < n) G[(size_t)r * n + c] = acc[i][j];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + kq + 4 * r;
+            if (row < n && c < n) G[(size_t)row * n + c] = acc[e][r];
         }
+    });
+}
+
+template <typename T, int RT>
+__global__ void __launch_bounds__(256, 2) k_gram_mfma(SetupArgs a) {
+    const int mat = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    switch (__builtin_amdgcn_readfirstlane(wave)) {
+        case 0: gram_mfma_wave<T, RT, 0>(a, mat, lane); break;
+        case 1: gram_mfma_wave<T, RT, 1>(a, mat, lane); break;
+        case 2: gram_mfma_wave<T, RT, 2>(a, mat, lane); break;
+        default: gram_mfma_wave<T, RT, 3>(a, mat, lane); break;
+    }
 }
 
 hipError_t rqp_launch_gram(const rqp_handle* h, const SetupArgs& a, hipStream_t s) {
+    // n <= 112: the float64 MFMA kernel (upper 16 x 16 tiles only, like k_factor_reg2 reads them)
     if (h->n <= 32) {
-        if (h->esz == 4) k_gram2<float, 2><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 2><<<h->nmat, 256, 0, s>>>(a);
+        if (h->esz == 4) k_gram_mfma<float, 2><<<h->nmat, 256, 0, s>>>(a); else k_gram_mfma<double, 2><<<h->nmat, 256, 0, s>>>(a);
         return hipGetLastError();
     }
     if (h->n <= 64) {
-        if (h->esz == 4) k_gram2<float, 4><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 4><<<h->nmat, 256, 0, s>>>(a);
+        if (h->esz == 4) k_gram_mfma<float, 4><<<h->nmat, 256, 0, s>>>(a); else k_gram_mfma<double, 4><<<h->nmat, 256, 0, s>>>(a);
         return hipGetLastError();
     }
     if (h->n <= 112 && h->ldn <= 112) {           // (the same predicate as rqp_launch_factor: k_factor_reg2 reads the upper blocks only)
-        if (h->esz == 4) k_gram2<float, 7><<<h->nmat, 256, 0, s>>>(a); else k_gram2<double, 7><<<h->nmat, 256, 0, s>>>(a);
+        if (h->esz == 4) k_gram_mfma<float, 7><<<h->nmat, 256, 0, s>>>(a); else k_gram_mfma<double, 7><<<h->nmat, 256, 0, s>>>(a);
         return hipGetLastError();
     }
 
