@@ -173,7 +173,11 @@ int rqp_create(rqp_handle** out, const rqp_dims* dims, const rqp_settings* setti
  * per-rho KKT inverses of ReLU_Layer.setup_matrices (reluqpth.py:40-78; here
  * K_j = (H + sigma I + A' diag(rho_j c) A)^-1 for every ladder entry, c_i = 1e3 on
  * rows with u_i - l_i <= eq_tol), zero state and rho_ind = argmin|rhos - rho|.
- * H [batch|1][n][n], g [batch][n], A [batch|1][m][n], l,u [batch][m], row-major.  */
+ * H [batch|1][n][n], g [batch][n], A [batch|1][m][n], l,u [batch][m], row-major.
+ * The inputs are read by kernels enqueued on `stream` (every one of them more than once:
+ * some handles keep no copy of A and build A'cA and the register image of A straight from
+ * the caller's buffer): they must stay valid and unchanged until that work has completed,
+ * like the operands of any stream-ordered call.  Nothing is read after that.           */
 int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const void* l,
               const void* u, void* stream);
 
