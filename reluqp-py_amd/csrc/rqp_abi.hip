@@ -109,6 +109,7 @@ void free_ws(rqp_handle* h) {
     h->ncont_h = nullptr;
     h->windowed = false;
     h->borrow_A = false;
+    h->kpack_direct = false;
     h->is_setup = false;
     h->order_valid = false;
     h->resident = false;
@@ -266,11 +267,19 @@ int select_kernels(rqp_handle* h) {
                   !h->st.check_infeasibility && !h->use_mfma;
     if (h->windowed) h->kwin = RQP_WINDOW;
     h->borrow_A = h->windowed && h->resident && h->st.scaling <= 0 && h->ldn == h->n;     // (rqp_common.h)
+    h->kpack_direct = h->windowed && h->resident && !h->k_direct && h->dims.tile_dtype != RQP_TILE_F16;
     if (h->use_mfma) h->kernel_name = h->mfmad ? "mfmad" : (h->mfmal ? "mfmal" : (h->mfma16 ? "mfma16" : "mfma"));
     else if (h->use_wave) h->kernel_name = "wave";
     else if (h->resident) h->kernel_name = "resident2";
     else if (h->resident64) h->kernel_name = "resident64";
     return RQP_OK;
+}
+
+// kpack_direct handles: the factor kernel's output is the register image of k_admm_res2
+void set_kp_image(const rqp_handle* h, SetupArgs& f) {
+    if (!h->kpack_direct) return;
+    f.kp_img = h->Kpack;
+    rqp_res2_kp_layout(h, &f.kp_cw, &f.kp_kr, &f.kp_kc);
 }
 
 // pack (QP.__init__ casts) -> G = A'cA -> K_j ladder -> kernel images, for new H and/or A (NULL: keep the packed copy).
@@ -279,19 +288,21 @@ int build_matrices(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     HIP_TRY(h, rqp_launch_pack_mats(h, a, s));
     if (h->st.scaling > 0) HIP_TRY(h, rqp_launch_ruiz(h, s));       // Ht, A, At scaled in place; D, E, c kept for the boundary
     if (a.A) HIP_TRY(h, rqp_launch_gram(h, a, s));                  // (NULL: a handle without a copy of A that keeps its A -- G = A'cA stands)
-    HIP_TRY(h, rqp_launch_factor(h, a, s));
-    if (h->resident) {
-        if (!h->Apack) {
-            size_t ae, ke, he;
-            rqp_res2_pack_elems(h, &ae, &ke, &he);
-            HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
-            if (ke) HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));   // (none with RQP_FLAG_LOW_MEMORY)
-            HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
-            if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
-            HIP_TRY(h, rqp_prepare_res2(h));
-        }
-        HIP_TRY(h, rqp_launch_pack_res2(h, a.A, nullptr, s));
+    if (h->resident && !h->Apack) {                                 // (before the factor launch: kpack_direct writes Kpack there)
+        size_t ae, ke, he;
+        rqp_res2_pack_elems(h, &ae, &ke, &he);
+        HIP_TRY(h, hipMalloc((void**)&h->Apack, ae * sizeof(float)));
+        if (ke) HIP_TRY(h, hipMalloc((void**)&h->Kpack, ke * sizeof(float)));   // (none with RQP_FLAG_LOW_MEMORY)
+        HIP_TRY(h, hipMalloc((void**)&h->Hpack, he * sizeof(float)));
+        if (h->dims.tile_dtype == RQP_TILE_F16) HIP_TRY(h, hipMalloc((void**)&h->Kscale, (size_t)h->nmat * h->nrho * sizeof(float)));
+        HIP_TRY(h, rqp_prepare_res2(h));
     }
+    {
+        SetupArgs f = a;
+        set_kp_image(h, f);
+        HIP_TRY(h, rqp_launch_factor(h, f, s));
+    }
+    if (h->resident) HIP_TRY(h, rqp_launch_pack_res2(h, a.A, nullptr, s));
     if (h->resident64) HIP_TRY(h, rqp_prepare_res64(h));
     if (h->use_mfma) {
         if (!h->W1img) {
@@ -403,7 +414,7 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     // A' (the streaming kernel's A dx operand and the wavefront kernel's column role): not on a windowed resident handle, whose
     // solve / iterate / residuals all run on k_admm_res2 and which refuses the certificate pass (0.5 GB and 0.4 ms at B = 4096)
     if (!(h->windowed && h->resident)) HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
-    {   // (+ a zeroed tail: the low-memory K load of the resident kernel reads up to one vector past a row's end)
+    if (!h->kpack_direct) {   // (+ a zeroed tail: the low-memory K load of the resident kernel reads up to one vector past a row's end)
         const size_t kb = nm * h->kwin * n * h->ldn * e;
         HIP_TRY(h, hipMalloc(&h->K, kb + 256));
         HIP_TRY(h, hipMemsetAsync((char*)h->K + kb, 0, 256, s));
@@ -599,6 +610,7 @@ static int refactor_windows(rqp_handle* h, int all, hipStream_t s) {
     HIP_TRY(h, rqp_launch_rewindow(h, all, s));
     SetupArgs f = make_setup_args(h, nullptr, nullptr, nullptr, nullptr, nullptr);
     f.only = h->cstat_d;
+    set_kp_image(h, f);
     HIP_TRY(h, rqp_launch_factor(h, f, s));
     if (h->resident) HIP_TRY(h, rqp_launch_pack_res2(h, nullptr, h->cstat_d, s));
     return RQP_OK;

@@ -74,6 +74,10 @@ struct rqp_handle {
     // read the caller's A during rqp_setup / rqp_update_mats (same stream order as every other input) -- 0.5 GB and 0.3 ms of
     // the headline batch's setup.  Needs the caller's row pitch to be the packed one (n % 4 == 0).
     bool borrow_A = false;
+    // ... and no row-major K(rho) table either: k_factor_reg2 writes every K_j in the lane-linear layout of Kpack (two halves of
+    // the rows through an LDS stage), k_pack_res2's K launch is gone (0.8 GB and 0.37 ms of the headline batch's setup).  Not with
+    // the fp16 tile (its scale needs the block maximum first) nor with RQP_FLAG_LOW_MEMORY (which keeps the TABLE instead).
+    bool kpack_direct = false;
     int32_t* wbase_d = nullptr;   // [nmat] ladder index of slot 0
     double* ax_d = nullptr;       // [B][m] A x of an instance that left its window (exact continuation)
     int32_t* cstat_d = nullptr;   // [B] 1: left its window, continue after the re-factor
@@ -156,6 +160,9 @@ struct SetupArgs {
     int kwin;                 // K slots per matrix; slot s <-> ladder index (wbase ? wbase[mat] : 0) + s
     const int32_t* wbase;
     const int32_t* only;      // [nmat] (NULL: all) build only the matrices with only[mat] != 0 (re-factor of a moved window)
+    // k_factor_reg2 writes K_j straight into the register image of k_admm_res2 (rqp_handle.kpack_direct; NULL: row-major table K)
+    float* kp_img;            // Kpack[mat][slot][pair][256][2]
+    int kp_cw, kp_kr, kp_kc;  // tile constants of the handle's Res2Cfg: columns per wave, K rows per lane, K columns per lane
 };
 
 // launchers (defined in the .hip files); return hipError_t of the launch
@@ -190,6 +197,7 @@ size_t rqp_generic_lds_bytes(const rqp_handle* h);
 // resident (register/LDS) variant, float32 only
 bool rqp_res2_fits(const rqp_handle* h);
 void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, size_t* h_elems);
+void rqp_res2_kp_layout(const rqp_handle* h, int* cw, int* kr, int* kc);
 hipError_t rqp_launch_pack_res2(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s);   // A_src NULL: Apack is kept
 hipError_t rqp_launch_solve_res2(const rqp_handle* h, const SolveArgs& a, hipStream_t s);
 

@@ -935,6 +935,15 @@ void rqp_res2_pack_elems(const rqp_handle* h, size_t* a_elems, size_t* k_elems, 
     }
 }
 
+void rqp_res2_kp_layout(const rqp_handle* h, int* cw, int* kr, int* kc) {
+    switch (res2_pick(h)) {
+        case 0: *cw = Cfg2C4::CW; *kr = Cfg2C4::KR; *kc = Cfg2C4::KC; break;
+        case 1: *cw = Cfg2M::CW; *kr = Cfg2M::KR; *kc = Cfg2M::KC; break;
+        case 3: *cw = Cfg2N::CW; *kr = Cfg2N::KR; *kc = Cfg2N::KC; break;
+        default: *cw = Cfg2C2::CW; *kr = Cfg2C2::KR; *kc = Cfg2C2::KC; break;
+    }
+}
+
 template <class C>
 static hipError_t pack_t(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s) {
     const size_t stage_ah = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
@@ -950,7 +959,7 @@ static hipError_t pack_t(const rqp_handle* h, const void* A_src, const int32_t* 
         if (!only)
             k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)A_src, (const float*)h->Ht,
                                                                           (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
-        if (!h->k_direct)       // (low-memory handles read K from the row-major table: only the (A, H) images)
+        if (!h->k_direct && !h->kpack_direct)       // (low-memory handles read K from the row-major table; kpack_direct: the factor kernel wrote the image)
             k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)nullptr, (const float*)h->Ht,
                                                                                (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, only);
     }

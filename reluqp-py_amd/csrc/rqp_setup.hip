@@ -673,6 +673,56 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     // (i, (d - i) mod RT): an upper block comes from the thread's own registers, a lower block (i, j), i > j, is the
     // transpose of block (j, i) of thread (tx, ty) -- slot j of the same pass -- and a diagonal block averages the two
     // roundings of (r, c) and (c, r), which both exist there.
+    if constexpr (std::is_same<T, float>::value) {
+        if (a.kp_img) {
+            // Straight into the register image of k_admm_res2 (rqp_resident2.hip, k_pack_res2's layout):
+            //   Kpack[mat][slot][pair = kp*KC + c][t = 64 w + lane][h] = K_j[CW w + KR rr + 2 kp + h][KC cc + c],  rr = lane >> 3, cc = lane & 7
+            // Two halves of the rows (waves 0-1, then 2-3 of the solve kernel) pass through a float stage in LDS of 2 CW x ldn
+            // elements -- with the whole matrix staged, four workgroups of this kernel would no longer share a CU --: the same
+            // transposing passes as below fill the stage, then all 256 threads gather the half's pairs (two thread groups take
+            // half of the pairs each) and write them as float2, 512 contiguous bytes per wave.
+            extern __shared__ __attribute__((aligned(16))) float kstage[];
+            const int CW = a.kp_cw, KR = a.kp_kr, KC = a.kp_kc, KE2 = (KR / 2) * KC, ldn = a.ldn;
+            float2* Kp = (float2*)a.kp_img + ((size_t)mat * a.kwin + jrho) * KE2 * 256;
+            for (int half = 0; half < 2; ++half) {
+                const int r0 = 2 * half * CW, r1 = r0 + 2 * CW;
+#pragma unroll
+                for (int d = 0; d < RT; ++d) {
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) {
+                        const int j = (d - i + RT) % RT;
+                        if (i <= j) tb[i][ty][tx] = mreg[i][j];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) {
+                        const int j = (d - i + RT) % RT;
+                        const int r = ty + 16 * i, c = tx + 16 * j;
+                        if (16 * i + 15 < r0 || 16 * i >= r1) continue;       // (uniform) a row block outside this half
+                        double v;
+                        if (i < j) v = mreg[i][j];
+                        else if (i > j) v = tb[j][tx][ty];
+                        else v = 0.5 * (mreg[i][i] + tb[i][tx][ty]);
+                        if (r >= r0 && r < r1 && r < n && c < ldn) kstage[(r - r0) * ldn + c] = (c < n) ? (float)(-v) : 0.f;
+                    }
+                }
+                __syncthreads();
+                const int tt = tid & 127, wl = tt >> 6, lane = tt & 63, rr = lane >> 3, cc = lane & 7;
+                const int tk = 64 * (2 * half + wl) + lane;
+                const int ph = (KE2 + 1) / 2, p0 = (tid >> 7) * ph, p1 = min(KE2, p0 + ph);
+                for (int pr = p0; pr < p1; ++pr) {
+                    const int lr = KR * rr + 2 * (pr / KC), c = KC * cc + pr % KC;
+                    const int r = r0 + CW * wl + lr;
+                    float2 v;
+                    v.x = (lr < CW && r < n && c < n) ? kstage[(CW * wl + lr) * ldn + c] : 0.f;
+                    v.y = (lr + 1 < CW && r + 1 < n && c < n) ? kstage[(CW * wl + lr + 1) * ldn + c] : 0.f;
+                    Kp[(size_t)pr * 256 + tk] = v;
+                }
+            }
+            return;
+        }
+    }
     T* K = (T*)a.K + ((size_t)mat * a.kwin + jrho) * n * a.ldn;
 #pragma unroll
     for (int d = 0; d < RT; ++d) {
@@ -698,7 +748,9 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
 
 template <typename T, int RT>
 static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
-    k_factor_reg2<T, RT><<<a.nmat * a.kwin, 256, 0, s>>>(a);
+    // (kpack_direct: + a float stage of half of the register image's rows; 17 KB static + <= 23 KB: four workgroups still share a CU)
+    const size_t stage = a.kp_img ? (size_t)2 * a.kp_cw * a.ldn * sizeof(float) : 0;
+    k_factor_reg2<T, RT><<<a.nmat * a.kwin, 256, stage, s>>>(a);
     return hipGetLastError();
 }
 
