@@ -57,6 +57,8 @@ CASES = [  # (precision, kernel, n, n_eq, n_ineq, feasible, settings)
     (torch.float32, "resident", 40, 10, 70, False, dict(max_iter=400)),
     (torch.float64, "generic", 30, 8, 50, True, dict(eps_abs=1e-7, max_iter=2000)),
     (torch.float32, "resident", 100, 25, 275, True, dict(eps_abs=1e-4)),
+    (torch.float32, "resident", 72, 18, 150, True, dict(eps_abs=1e-4)),              # the (80, 320) tile: direct K image, borrowed A
+    (torch.float32, "resident", 33, 8, 60, False, dict(max_iter=400)),               # padded rows (ldn = 36 != n): direct K image, copied A
     (torch.float64, "resident", 10, 5, 15, False, dict(max_iter=600)),               # k_admm_res64
     (torch.float64, "resident", 40, 10, 70, False, dict(max_iter=400, check_interval=10)),
     (torch.float64, "resident", 100, 25, 275, True, dict(eps_abs=1e-6)),
