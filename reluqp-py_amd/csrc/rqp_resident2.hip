@@ -818,56 +818,25 @@ __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD) k_admm_res2(SolveArgs 
 
 // ---------------------------------------------------------------------------- packing
 // Lane-linear images written once at setup:
-//   Apack[mat][pair = rp*CQ + c][t][2]      = A[RB*pl + 2rp + h][CW*w + CQ*q + c]
+//   Apack[mat][pair = rp*CQ + c][t][2]      = A[RB*pl + 2rp + h][CW*w + CQ*q + c]          (k_pack_res2_ah)
 //   Kpack[mat][j][pair = kp*KC + c][t][2]   = K_j[CW*w + KR*rr + 2kp + h][KC*cc + c]   (0 when KR*rr + 2kp + h >= CW)
 //   Hpack[mat][c][t][4]                     = H[HR*pl + 0..3][CW*w + CQ*q + c]
 //   KH: Kpack holds fp16 pairs (one dword per row pair) of K_j / Kscale[mat][j], Kscale = 2^e with max|K_j| / Kscale <= 2^14
 template <class C, bool KH>
-__global__ void k_pack_res2(int n, int m, int ldn, int nrho, int xoff, const float* __restrict__ A, const float* __restrict__ Ht,
-                            const float* __restrict__ K, float* __restrict__ Apack, float* __restrict__ Kpack,
-                            float* __restrict__ Hpack, float* __restrict__ Kscale, const int32_t* __restrict__ only) {
-    constexpr int RB = C::RB, CQ = C::CQ, KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, AE2 = C::AE2, KE2 = C::KE2, HU = C::HU, HR = C::HR;
+__global__ void k_pack_res2(int n, int ldn, int nrho, const float* __restrict__ K, float* __restrict__ Kpack, float* __restrict__ Kscale,
+                            const int32_t* __restrict__ only) {
+    constexpr int KR = C::KR, KC = C::KC, NT = C::NT, CW = C::CW, KE2 = C::KE2;
     const int mat = blockIdx.y;                                    // (nrho here = K slots per matrix, rqp_handle.kwin)
     if (only && !only[mat]) return;                                // re-pack of moved windows only
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const int q = lane & 1, pl = lane >> 1, rr = lane >> 3, cc = lane & 7;
-    const float* Am = A + (size_t)mat * m * ldn;
-    const float* Hm = Ht + (size_t)mat * n * ldn;
-    // every source matrix passes through LDS: coalesced row reads in, the lane-linear gather runs on LDS (the direct
-    // gather from global memory was 4-byte accesses 52 B or a whole row apart: 5 ms per 4096 instances)
-    // Two launches: the (A, H) blocks (xoff = 0, stage = max(m, n) * ldn floats: 125 KB at m = 300, one workgroup per CU) and
-    // the nrho K_j blocks per matrix (xoff = 1, stage = n * ldn floats: 3 workgroups per CU -- launched together with the
-    // big stage they ran one per CU as well: 2.6 ms for 4096 x 18 matrices)
+    const int rr = lane >> 3, cc = lane & 7;
+    // The K_j images from the row-major table (full-ladder, fp16-tile and non-windowed handles; a windowed float32 handle gets them
+    // from the factor kernel: rqp_handle.kpack_direct).  The source passes through LDS: coalesced row reads in, the lane-linear
+    // gather runs on LDS (the direct gather from global memory was 4-byte accesses 52 B or a whole row apart: 5 ms per 4096
+    // instances); stage = n * ldn floats, 3 workgroups per CU.  The (A, H) images: k_pack_res2_ah below.
     extern __shared__ __attribute__((aligned(16))) float stage[];
-    const int bx = blockIdx.x + xoff;
-    if (bx == 0) {
-        if (A) {                                                   // (NULL: rqp_update_mats with a new H only -- Apack stands)
-            for (int i = t; i < m * ldn; i += NT) stage[i] = Am[i];
-            __syncthreads();
-            f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
-            for (int pair = 0; pair < AE2; ++pair) {
-                const int r = RB * pl + 2 * (pair / CQ), c = CW * w + CQ * q + pair % CQ;
-                f2 v;
-                v.x = (r < m && c < n) ? stage[r * ldn + c] : 0.f;
-                v.y = (r + 1 < m && c < n) ? stage[(r + 1) * ldn + c] : 0.f;
-                Ap[(size_t)pair * NT + t] = v;
-            }
-            __syncthreads();
-        }
-        for (int i = t; i < n * ldn; i += NT) stage[i] = Hm[i];
-        __syncthreads();
-        float4* Hp = (float4*)(Hpack + (size_t)mat * HU * NT * 4);
-        for (int c0 = 0; c0 < CQ; ++c0) {                              // unit c0 = (H[HR*pl + 0..3][col(c0)]) : one b128 per column
-            const int c = CW * w + CQ * q + c0;
-            float hv[HR];
-            for (int h = 0; h < HR; ++h) {
-                const int r = HR * pl + h;
-                hv[h] = (r < n && c < n) ? stage[c * ldn + r] : 0.f;   // H[r][c] = Ht[c][r]
-            }
-            Hp[(size_t)c0 * NT + t] = (float4){hv[0], hv[1], hv[2], hv[3]};
-        }
-    } else {
-        const int j = bx - 1;
+    {
+        const int j = blockIdx.x;                                  // K slot
         const float* Kj = K + ((size_t)mat * nrho + j) * n * ldn;
         for (int i = t; i < n * ldn; i += NT) stage[i] = Kj[i];
         __syncthreads();
@@ -899,6 +868,62 @@ __global__ void k_pack_res2(int n, int m, int ldn, int nrho, int xoff, const flo
                 ((h2*)Kp)[(size_t)pair * NT + t] = (h2){(_Float16)(v.x * inv_scale), (_Float16)(v.y * inv_scale)};
             else
                 ((f2*)Kp)[(size_t)pair * NT + t] = v;
+        }
+    }
+}
+
+
+// The (A, H) images, round 3 late: one workgroup per QUARTER of the row groups of A (pl in [8 ch, 8 ch + 8): rows [RB 8 ch, RB 8 (ch + 1)),
+// i.e. lanes [16 ch, 16 ch + 16) of every wave of the solve kernel) plus one for H -- stages of M / 4 x ldn and n x ldn floats
+// (32 / 40 KB on the big tile: 3-4 workgroups per CU) instead of one workgroup per matrix with the whole of A staged (125 KB, one
+// per CU: 0.42 ms for the headline batch).  Thread t of an A workgroup = (part = t >> 6, w = (t >> 4) & 3, l16 = t & 15): pairs part,
+// part + 4, ... of lane 16 ch + l16 of wave w; 128 contiguous bytes per 16 threads.
+template <class C>
+__global__ void k_pack_res2_ah(int n, int m, int ldn, const float* __restrict__ A, const float* __restrict__ Ht,
+                               float* __restrict__ Apack, float* __restrict__ Hpack) {
+    constexpr int RB = C::RB, CQ = C::CQ, NT = C::NT, CW = C::CW, AE2 = C::AE2, HU = C::HU, HR = C::HR, RCH = C::M / 4;
+    const int mat = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float stage[];
+    if (ch < 4) {
+        if (!A) return;                                            // (rqp_update_mats with a new H only -- Apack stands)
+        const int r0 = RCH * ch;
+        const float* Am = A + (size_t)mat * m * ldn + (size_t)r0 * ldn;
+        const int avail = (m - r0) * ldn;                          // floats of A from row r0 on (<= 0: a chunk of padding rows)
+        if ((((size_t)Am) & 15) == 0) {                             // 16-byte loads (ldn % 4 == 0; 4-byte loads ran this kernel at 3 TB/s)
+            for (int i = 4 * t; i < RCH * ldn; i += 4 * NT)
+                *(float4*)(stage + i) = (i < avail) ? *(const float4*)(Am + i) : (float4){0.f, 0.f, 0.f, 0.f};     // (avail % 4 == 0)
+        } else {
+            for (int i = t; i < RCH * ldn; i += NT) stage[i] = (i < avail) ? Am[i] : 0.f;
+        }
+        __syncthreads();
+        const int l16 = t & 15, w = (t >> 4) & 3, part = t >> 6;
+        const int lane = 16 * ch + l16, q = lane & 1, pl = lane >> 1, tk = 64 * w + lane;
+        f2* Ap = (f2*)(Apack + (size_t)mat * AE2 * NT * 2);
+        for (int pair = part; pair < AE2; pair += 4) {
+            const int lr = RB * pl + 2 * (pair / CQ) - r0, c = CW * w + CQ * q + pair % CQ;      // rows >= m hold zeros in the stage
+            f2 v;
+            v.x = (c < n) ? stage[lr * ldn + c] : 0.f;
+            v.y = (c < n) ? stage[(lr + 1) * ldn + c] : 0.f;
+            Ap[(size_t)pair * NT + tk] = v;
+        }
+    } else {
+        const int w = t >> 6, lane = t & 63, q = lane & 1, pl = lane >> 1;
+        const float* Hm = Ht + (size_t)mat * n * ldn;
+        if ((((size_t)Hm) & 15) == 0) {
+            for (int i = 4 * t; i < n * ldn; i += 4 * NT) *(float4*)(stage + i) = *(const float4*)(Hm + i);
+        } else {
+            for (int i = t; i < n * ldn; i += NT) stage[i] = Hm[i];
+        }
+        __syncthreads();
+        float4* Hp = (float4*)(Hpack + (size_t)mat * HU * NT * 4);
+        for (int c0 = 0; c0 < CQ; ++c0) {                              // unit c0 = (H[HR*pl + 0..3][col(c0)]) : one b128 per column
+            const int c = CW * w + CQ * q + c0;
+            float hv[HR];
+            for (int h = 0; h < HR; ++h) {
+                const int r = HR * pl + h;
+                hv[h] = (r < n && c < n) ? stage[c * ldn + r] : 0.f;   // H[r][c] = Ht[c][r]
+            }
+            Hp[(size_t)c0 * NT + t] = (float4){hv[0], hv[1], hv[2], hv[3]};
         }
     }
 }
@@ -946,22 +971,16 @@ void rqp_res2_kp_layout(const rqp_handle* h, int* cw, int* kr, int* kc) {
 
 template <class C>
 static hipError_t pack_t(const rqp_handle* h, const void* A_src, const int32_t* only, hipStream_t s) {
-    const size_t stage_ah = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
+    const size_t stage_ah = (size_t)(C::M / 4 > h->n ? C::M / 4 : h->n) * h->ldn * sizeof(float);
     const size_t stage_k = (size_t)h->n * h->ldn * sizeof(float);
     // only != NULL: the K blocks of the matrices whose window moved (A and H have not changed)
+    if (!only)
+        k_pack_res2_ah<C><<<dim3(5, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, (const float*)A_src, (const float*)h->Ht, h->Apack, h->Hpack);
     if (h->dims.tile_dtype == RQP_TILE_F16) {
-        if (!only)
-            k_pack_res2<C, true><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)A_src, (const float*)h->Ht,
-                                                                         (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, nullptr);
-        k_pack_res2<C, true><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)nullptr, (const float*)h->Ht,
-                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, h->Kscale, only);
+        k_pack_res2<C, true><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->ldn, h->kwin, (const float*)h->K, h->Kpack, h->Kscale, only);
     } else {
-        if (!only)
-            k_pack_res2<C, false><<<dim3(1, h->nmat), C::NT, stage_ah, s>>>(h->n, h->m, h->ldn, h->kwin, 0, (const float*)A_src, (const float*)h->Ht,
-                                                                          (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, nullptr);
         if (!h->k_direct && !h->kpack_direct)       // (low-memory handles read K from the row-major table; kpack_direct: the factor kernel wrote the image)
-            k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->m, h->ldn, h->kwin, 1, (const float*)nullptr, (const float*)h->Ht,
-                                                                               (const float*)h->K, h->Apack, h->Kpack, h->Hpack, nullptr, only);
+            k_pack_res2<C, false><<<dim3(h->kwin, h->nmat), C::NT, stage_k, s>>>(h->n, h->ldn, h->kwin, (const float*)h->K, h->Kpack, nullptr, only);
     }
     return hipGetLastError();
 }
@@ -977,8 +996,13 @@ hipError_t rqp_launch_pack_res2(const rqp_handle* h, const void* A_src, const in
 template <class C>
 static hipError_t prepare_t(const rqp_handle* h) {
     const size_t lds = C::lds_bytes();
-    {   // pack kernel: its LDS stage holds a whole source matrix (up to m x ldn floats = 128 KB on the big tile)
-        const size_t stage = (size_t)(h->m > h->n ? h->m : h->n) * h->ldn * sizeof(float);
+    {
+        const size_t stage_ah = (size_t)(C::M / 4 > h->n ? C::M / 4 : h->n) * h->ldn * sizeof(float);
+        hipError_t ae = rqp_raise_lds_limit((const void*)k_pack_res2_ah<C>, stage_ah);
+        if (ae != hipSuccess) return ae;
+    }
+    {   // K pack kernel: its LDS stage holds one K_j (n x ldn floats)
+        const size_t stage = (size_t)h->n * h->ldn * sizeof(float);
         hipError_t pe = (h->dims.tile_dtype == RQP_TILE_F16)
                             ? rqp_raise_lds_limit((const void*)k_pack_res2<C, true>, (size_t)stage)
                             : rqp_raise_lds_limit((const void*)k_pack_res2<C, false>, (size_t)stage);
