@@ -412,8 +412,9 @@ int rqp_setup(rqp_handle* h, const void* H, const void* g, const void* A, const 
     HIP_TRY(h, hipMalloc(&h->Ht, nm * n * h->ldn * e));
     if (!h->borrow_A) HIP_TRY(h, hipMalloc(&h->A, nm * m * h->ldn * e));     // (rqp_common.h: borrow_A)
     // A' (the streaming kernel's A dx operand and the wavefront kernel's column role): not on a windowed resident handle, whose
-    // solve / iterate / residuals all run on k_admm_res2 and which refuses the certificate pass (0.5 GB and 0.4 ms at B = 4096)
-    if (!(h->windowed && h->resident)) HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
+    // solve / iterate / residuals all run on k_admm_res2 / k_admm_res64 (neither reads A') and which refuses the certificate pass
+    // (float32: 0.5 GB and 0.4 ms at B = 4096; float64: 1 GB and 1 ms)
+    if (!(h->windowed && (h->resident || h->resident64))) HIP_TRY(h, hipMalloc(&h->At, nm * n * h->ldm * e));
     if (!h->kpack_direct) {   // (+ a zeroed tail: the low-memory K load of the resident kernel reads up to one vector past a row's end)
         const size_t kb = nm * h->kwin * n * h->ldn * e;
         HIP_TRY(h, hipMalloc(&h->K, kb + 256));
