@@ -717,40 +717,43 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
             //   Kpack[mat][slot][pair = kp*KC + c][t = 64 w + lane][h] = K_j[CW w + KR rr + 2 kp + h][KC cc + c],  rr = lane >> 3, cc = lane & 7
             // Two halves of the rows (waves 0-1, then 2-3 of the solve kernel) pass through a float stage in LDS of 2 CW x ldn
             // elements -- with the whole matrix staged, four workgroups of this kernel would no longer share a CU --: the same
-            // transposing passes as below fill the stage, then all 256 threads gather the half's pairs (two thread groups take
-            // half of the pairs each) and write them as float2, 512 contiguous bytes per wave.
+            // stage is filled (below), then all 256 threads gather the half's pairs (two thread groups take half of the pairs
+            // each) and write them as float2, 512 contiguous bytes per wave.
             extern __shared__ __attribute__((aligned(16))) float kstage[];
             const int CW = a.kp_cw, KR = a.kp_kr, KC = a.kp_kc, KE2 = (KR / 2) * KC, ldn = a.ldn;
             float2* Kp = (float2*)a.kp_img + ((size_t)mat * a.kwin + jrho) * KE2 * 256;
+            // The stage is filled WITHOUT the transposing passes of the table path: an upper block's element (r, c) is also element
+            // (c, r) of the lower block (the sweep keeps M symmetric; the table path reads exactly that value through LDS), so its
+            // owner writes both; only the diagonal blocks need the partner's rounding (their average), one exchange for all RT.
+            float fv[RT][RT];                                          // K_j = -M in float32 (upper blocks; the doubles are dead from here)
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < RT; ++i) tb[i][ty][tx] = mreg[i][i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = i; j < RT; ++j) fv[i][j] = (float)(-(i == j ? 0.5 * (mreg[i][i] + tb[i][tx][ty]) : mreg[i][j]));
             for (int half = 0; half < 2; ++half) {
                 const int r0 = 2 * half * CW, r1 = r0 + 2 * CW;
+                if (half) __syncthreads();                              // (the gather of the first half is done with the stage)
 #pragma unroll
-                for (int d = 0; d < RT; ++d) {
-                    __syncthreads();
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) {
-                        const int j = (d - i + RT) % RT;
-                        if (i <= j) tb[i][ty][tx] = mreg[i][j];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) {
-                        const int j = (d - i + RT) % RT;
+                    for (int j = i; j < RT; ++j) {
                         const int r = ty + 16 * i, c = tx + 16 * j;
-                        if (16 * i + 15 < r0 || 16 * i >= r1) continue;       // (uniform) a row block outside this half
-                        double v;
-                        if (i < j) v = mreg[i][j];
-                        else if (i > j) v = tb[j][tx][ty];
-                        else v = 0.5 * (mreg[i][i] + tb[i][tx][ty]);
-                        if (r >= r0 && r < r1 && r < n && c < ldn) kstage[(r - r0) * ldn + c] = (c < n) ? (float)(-v) : 0.f;
+                        const float v = fv[i][j];
+                        if (r >= r0 && r < r1 && r < n && c < ldn) kstage[(r - r0) * ldn + c] = (c < n) ? v : 0.f;
+                        if (i != j && c >= r0 && c < r1 && c < n && r < ldn) kstage[(c - r0) * ldn + r] = (r < n) ? v : 0.f;
                     }
-                }
                 __syncthreads();
                 const int tt = tid & 127, wl = tt >> 6, lane = tt & 63, rr = lane >> 3, cc = lane & 7;
                 const int tk = 64 * (2 * half + wl) + lane;
                 const int ph = (KE2 + 1) / 2, p0 = (tid >> 7) * ph, p1 = min(KE2, p0 + ph);
+                int kp2 = 2 * (p0 / KC), c0 = p0 % KC;                  // (KC is a run-time value here: one division, then counters)
                 for (int pr = p0; pr < p1; ++pr) {
-                    const int lr = KR * rr + 2 * (pr / KC), c = KC * cc + pr % KC;
+                    const int lr = KR * rr + kp2, c = KC * cc + c0;
+                    if (++c0 == KC) { c0 = 0; kp2 += 2; }
                     const int r = r0 + CW * wl + lr;
                     float2 v;
                     v.x = (lr < CW && r < n && c < n) ? kstage[(CW * wl + lr) * ldn + c] : 0.f;
