@@ -641,15 +641,18 @@ __global__ void __launch_bounds__(256) k_factor_fast(SetupArgs a) {
 // FMAs per step, 56 instead of 98 matrix registers -> 4 workgroups per CU): element (r, c) of a lower block is element
 // (c, r) of thread (tx, ty)'s upper block.  Row k is posted by its two sets of owners: the threads with ty == ko hold
 // (k, c) for the blocks j >= kb, the threads with tx == ko hold (c, k) = (k, c) for the blocks i < kb.  [7.6 -> ms below]
-template <typename T, int RT>
-__global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
-    constexpr int NMAX = 16 * RT;
+// TG: side of the thread grid.  16 (256 threads, four waves) for n <= 112; 8 (ONE wave per matrix, RT = 4: the barrier of a
+// step is free) for n <= 32 on the table path -- 256 threads on a 32 x 32 matrix hold 3 elements each and spend a step on its
+// barrier: 0.33 ms for the 40 960 inversions of the config-4 batch.
+template <typename T, int RT, int TG = 16>
+__global__ void __launch_bounds__(TG * TG, TG == 16 ? 4 : 8) k_factor_reg2(SetupArgs a) {
+    constexpr int NMAX = TG * RT;
     __shared__ __attribute__((aligned(16))) double rowbuf[2][NMAX];
-    __shared__ __attribute__((aligned(16))) double tb[RT][16][17];       // one output pass: RT blocks, closed under transposition
+    __shared__ __attribute__((aligned(16))) double tb[RT][TG][TG + 1];       // one output pass: RT blocks, closed under transposition
     const int n = a.n;
     const int mat = blockIdx.x / a.kwin, jrho = blockIdx.x % a.kwin;     // jrho: K slot; ladder index = window base + slot
     if (a.only && !a.only[mat]) return;                                   // (uniform) re-factor of moved windows only
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, tx = tid & (TG - 1), ty = tid / TG;
     const T* Ht = (const T*)a.Ht + (size_t)mat * n * a.ldn;
     const double* G = a.G + (size_t)mat * n * n;
     const double rho = a.rhos[(a.wbase ? a.wbase[mat] : 0) + jrho];
@@ -658,7 +661,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = i; j < RT; ++j) {
-            const int r = ty + 16 * i, c = tx + 16 * j;
+            const int r = ty + TG * i, c = tx + TG * j;
             mreg[i][j] = 0.0;
             if (r < n && c < n) mreg[i][j] = (double)Ht[(size_t)r * a.ldn + c] + (r == c ? a.sigma : 0.0) + rho * G[(size_t)r * n + c];
         }
@@ -667,15 +670,15 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     auto step = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if (k < n) {                                                      // uniform
-            constexpr int kb = k / 16, ko = k % 16;                       // row / column block and offset of the pivot
+            constexpr int kb = k / TG, ko = k % TG;                       // row / column block and offset of the pivot
             double* rb = rowbuf[k & 1];
             if (ty == ko) {                                               // (k, c) for c in the blocks j >= kb
 #pragma unroll
-                for (int j = kb; j < RT; ++j) rb[tx + 16 * j] = mreg[kb][j];
+                for (int j = kb; j < RT; ++j) rb[tx + TG * j] = mreg[kb][j];
             }
             if (tx == ko) {                                               // (k, c) = (c, k) for c in the blocks i < kb
 #pragma unroll
-                for (int i = 0; i < kb; ++i) rb[ty + 16 * i] = mreg[i][kb];
+                for (int i = 0; i < kb; ++i) rb[ty + TG * i] = mreg[i][kb];
             }
             __syncthreads();
             // 1 / d: hardware reciprocal + two Newton steps (5 instructions; the IEEE division sequence is ~15, and every
@@ -686,9 +689,9 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
             p = fma(p, fma(-dk, p, 1.0), p);
             double rr[RT], tc[RT];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) rr[i] = rb[ty + 16 * i];
+            for (int i = 0; i < RT; ++i) rr[i] = rb[ty + TG * i];
 #pragma unroll
-            for (int j = 0; j < RT; ++j) tc[j] = rb[tx + 16 * j];
+            for (int j = 0; j < RT; ++j) tc[j] = rb[tx + TG * j];
 #pragma unroll
             for (int j = 0; j < RT; ++j) tc[j] = -tc[j] * p;
 #pragma unroll
@@ -711,7 +714,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     // (i, (d - i) mod RT): an upper block comes from the thread's own registers, a lower block (i, j), i > j, is the
     // transpose of block (j, i) of thread (tx, ty) -- slot j of the same pass -- and a diagonal block averages the two
     // roundings of (r, c) and (c, r), which both exist there.
-    if constexpr (std::is_same<T, float>::value) {
+    if constexpr (std::is_same<T, float>::value && TG == 16) {
         if (a.kp_img) {
             // Straight into the register image of k_admm_res2 (rqp_resident2.hip, k_pack_res2's layout):
             //   Kpack[mat][slot][pair = kp*KC + c][t = 64 w + lane][h] = K_j[CW w + KR rr + 2 kp + h][KC cc + c],  rr = lane >> 3, cc = lane & 7
@@ -741,7 +744,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int j = i; j < RT; ++j) {
-                        const int r = ty + 16 * i, c = tx + 16 * j;
+                        const int r = ty + TG * i, c = tx + TG * j;
                         const float v = fv[i][j];
                         if (r >= r0 && r < r1 && r < n && c < ldn) kstage[(r - r0) * ldn + c] = (c < n) ? v : 0.f;
                         if (i != j && c >= r0 && c < r1 && c < n && r < ldn) kstage[(c - r0) * ldn + r] = (r < n) ? v : 0.f;
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int j = (d - i + RT) % RT;
-            const int r = ty + 16 * i, c = tx + 16 * j;
+            const int r = ty + TG * i, c = tx + TG * j;
             double v;
             if (i < j) v = mreg[i][j];
             else if (i > j) v = tb[j][tx][ty];                            // M[c][r]: thread (tx, ty), block (j, i)
@@ -787,11 +790,11 @@ __global__ void __launch_bounds__(256, 4) k_factor_reg2(SetupArgs a) {
     }
 }
 
-template <typename T, int RT>
+template <typename T, int RT, int TG = 16>
 static hipError_t launch_factor_reg2(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     // (kpack_direct: + a float stage of half of the register image's rows; 17 KB static + <= 23 KB: four workgroups still share a CU)
     const size_t stage = a.kp_img ? (size_t)2 * a.kp_cw * a.ldn * sizeof(float) : 0;
-    k_factor_reg2<T, RT><<<a.nmat * a.kwin, 256, stage, s>>>(a);
+    k_factor_reg2<T, RT, TG><<<a.nmat * a.kwin, TG * TG, stage, s>>>(a);
     return hipGetLastError();
 }
 
@@ -806,6 +809,7 @@ static hipError_t launch_factor_fast(rqp_handle* h, const SetupArgs& a, hipStrea
 
 hipError_t rqp_launch_factor(rqp_handle* h, const SetupArgs& a, hipStream_t s) {
     const int n = h->n;
+    if (n <= 32 && !a.kp_img) return h->esz == 4 ? launch_factor_reg2<float, 4, 8>(h, a, s) : launch_factor_reg2<double, 4, 8>(h, a, s);
     if (n <= 32) return h->esz == 4 ? launch_factor_reg2<float, 2>(h, a, s) : launch_factor_reg2<double, 2>(h, a, s);
     if (n <= 64) return h->esz == 4 ? launch_factor_reg2<float, 4>(h, a, s) : launch_factor_reg2<double, 4>(h, a, s);
     if (n <= 112 && h->ldn <= 112)
