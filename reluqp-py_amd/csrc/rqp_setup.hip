@@ -282,7 +282,7 @@ constexpr int gm_tile_J(int g, int RT) { int I = 0; while (g >= RT - I) { g -= R
 
 template <typename T, int RT, int W>
 __device__ __forceinline__ void gram_mfma_wave(const SetupArgs& a, int mat, int lane) {
-    constexpr int NTILE = RT * (RT + 1) / 2, TPW = (NTILE - W + 3) / 4, KU = 4;
+    constexpr int NTILE = RT * (RT + 1) / 2, TPW = (NTILE - W + 3) / 4, KU = (sizeof(T) == 4) ? 2 : 4;
     const int n = a.n, m = a.m, ldn = a.ldn, i16 = lane & 15, kq = lane >> 4;
     const T* A = (const T*)a.A + (size_t)mat * m * ldn;
     const T* cv = (const T*)a.c + (size_t)mat * m;                       // shared mats: instance 0's pattern (mat = 0)
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gram_mfma_wave(const SetupArgs& a, int mat, int 
 }
 
 template <typename T, int RT>
-__global__ void __launch_bounds__(256, 2) k_gram_mfma(SetupArgs a) {
+__global__ void __launch_bounds__(256, (sizeof(T) == 4) ? 3 : 2) k_gram_mfma(SetupArgs a) {
     const int mat = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     switch (__builtin_amdgcn_readfirstlane(wave)) {
         case 0: gram_mfma_wave<T, RT, 0>(a, mat, lane); break;
