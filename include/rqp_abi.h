@@ -100,9 +100,10 @@ typedef struct rqp_dims {
 
 /* rqp_dims.flags */
 enum {
-    RQP_FLAG_LOW_MEMORY = 1,  /* resident float32 kernel: read K(rho) straight from the row-major table instead of a packed
-                                 lane-linear copy: less workspace and setup time for ~1 % more solve time; results are
-                                 bit-identical                                                                      */
+    RQP_FLAG_LOW_MEMORY = 1,  /* resident float32 kernel: keep K(rho) as the row-major table (n x ldn per entry) and load it
+                                 from there, instead of the larger lane-linear register image (padded to the kernel's tile):
+                                 less workspace for ~1 % more solve time; results are bit-identical.  (A windowed handle
+                                 holds ONE of the two: by default the factor kernel writes the register image directly.)  */
     RQP_FLAG_FULL_LADDER = 2  /* build K(rho) for EVERY entry of the rho ladder of every matrix, as the reference does
                                  (reluqpth.py:52-78).  Default for batches of >= 32 per-instance matrices on the resident
                                  float32 / streaming kernels: a WINDOW of 5 entries around each instance's index
