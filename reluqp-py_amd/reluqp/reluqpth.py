@@ -159,8 +159,8 @@ class ReLU_QP(object):
         float32 accumulation, state and residuals: rqp_abi.h RQP_TILE_BF16).  ``devices=[0, 1, ...]`` splits a batch
         contiguously over several GPUs inside this process (one handle and stream per device, results gathered on
         devices[0]; no collective -- reluqp/multidevice.py).  ``low_memory=True`` (rqp_dims.flags RQP_FLAG_LOW_MEMORY): the
-        resident float32 kernel reads K(rho) from the factor kernel's table instead of a packed copy -- 43 % less workspace,
-        12 % less setup time, 1 % more solve time, bit-identical results.  ``full_ladder=True`` (RQP_FLAG_FULL_LADDER): build
+        resident float32 kernel keeps and reads K(rho) as the row-major table instead of the larger tile-padded register
+        image -- ~12 % less workspace, 1 % more solve time, bit-identical results.  ``full_ladder=True`` (RQP_FLAG_FULL_LADDER): build
         K(rho) for every entry of the rho ladder of every matrix as the reference does (reluqpth.py:52-78); by default batches
         of >= 32 per-instance matrices keep a window of 5 entries around each instance's index and re-factor on demand
         (bit-identical results, ~3x less setup time and workspace; solve() then synchronises the stream, so use
