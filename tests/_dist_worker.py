@@ -31,7 +31,7 @@ def main():
     elapsed = 0.25 * (rank + 1)                       # synthetic per-rank time: the report takes the MAX
     cpu = torch.device("cpu")
     el, extra, tot_it, tot_solved, tot_q = D.reduce_report(
-        dist, cpu, elapsed, ref["iter"].sum(), sum(s == "solved" for s in ref["status"]), size, extra_max=[float(rank)])
+        dist, cpu, elapsed, ref["iter"].sum(), sum(s == "solved" for s in ref["status"]), size, extra_max=[float(rank), -elapsed])      # (a minimum rides along as the maximum of the negated value: bench.py's per_gpu)
     xs_all = D.gather_shards(dist, torch.from_numpy(ref["x"]), total, rank, world)
     it_all = D.gather_shards(dist, torch.from_numpy(ref["iter"]), total, rank, world)
     if rank == 0:
